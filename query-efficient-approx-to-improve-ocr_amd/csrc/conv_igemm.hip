@@ -1,0 +1,285 @@
+// Implicit-GEMM convolution / GEMM on the gfx950 fp32 matrix cores.
+//
+//   C[m][n] = sum_k A[m][k] * Wt[n][k]      m = (b,oh,ow) output pixel, n = output channel,
+//                                            k = (kh,kw,c) filter tap x input channel.
+// A is never materialised: every K-slice of 32 channels of one filter tap is gathered
+// straight from the NHWC input (zero outside the image) into an LDS tile, the filter slice
+// into a second one, and each wave runs v_mfma_f32_32x32x2_f32 over its 64x64 (or 64x32)
+// accumulator block.  K is consumed in a permuted order inside every group of 8 so that a
+// lane fetches its 4 A (B) values of four consecutive MFMAs with one ds_read_b128:
+// lane (r = l&31, h = l>>5), MFMA step s  ->  k = 4h + s  on both operands.
+//
+// Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); 2*M*N*K algorithmic flops/launch.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  float* y;
+  const float* scale;
+  const float* bias;
+  const float* mask;
+  int B, H, W, Cin, OH, OW, N, KH, KW, pad_h, pad_w, stride_h, stride_w;
+  int ldx, ldy, ldmask, relu, accumulate, out_mode;
+  int M, K, n_tiles, m_tiles;
+};
+
+constexpr int BK = 32;      // K-slice per stage (floats)
+constexpr int LDS_LD = 36;  // padded LDS row (floats): 144 B keeps b128 reads conflict-free
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int TM = BM / WGM, TN = BN / WGN;  // wave tile
+  constexpr int MI = TM / 32, NJ = TN / 32;    // 32x32 accumulator tiles per wave
+  constexpr int A_LD = BM / 32;                // float4 gathers per thread per stage (A)
+  constexpr int B_LD = BN / 32;                // (B)
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][BM][LDS_LD]
+  float* Bs = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int nwg = p.m_tiles * p.n_tiles;
+  const int tile = qea_xcd_swizzle(blockIdx.x, nwg);
+  const int tile_m = tile / p.n_tiles;
+  const int tile_n = tile % p.n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread gather coordinates (fixed over the K loop) ----
+  const int lrow = tid >> 3;  // 0..31
+  const int kc = tid & 7;     // which float4 of the 32-float K-slice
+  int a_pix[A_LD];            // b*H*W, or -1 when the row is past M
+  int a_ih0[A_LD], a_iw0[A_LD];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < p.M) {
+      const int b = m / ohw;
+      const int rem = m - b * ohw;
+      const int oh = rem / p.OW;
+      const int ow = rem - oh * p.OW;
+      a_pix[i] = b * p.H * p.W;
+      a_ih0[i] = oh * p.stride_h - p.pad_h;
+      a_iw0[i] = ow * p.stride_w - p.pad_w;
+    } else {
+      a_pix[i] = -1;
+      a_ih0[i] = 0;
+      a_iw0[i] = 0;
+    }
+  }
+  const float* b_ptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int n = n0 + lrow + 32 * j;
+    b_ptr[j] = (n < p.N) ? (p.w + (size_t)n * p.K + kc * 4) : nullptr;
+  }
+
+  const int cin_steps = p.Cin / BK;
+  const int KT = p.KH * p.KW * cin_steps;
+
+  f32x4 a_reg[A_LD], b_reg[B_LD];
+  auto gather = [&](int kt) {
+    const int tap = kt / cin_steps;
+    const int c0 = (kt - tap * cin_steps) * BK;
+    const int kh = tap / p.KW;
+    const int kw = tap - kh * p.KW;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+      const bool ok = (a_pix[i] >= 0) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float* src = p.x + (size_t)(a_pix[i] + ih * p.W + iw) * p.ldx + c0 + kc * 4;
+        v = *reinterpret_cast<const f32x4*>(src);
+      }
+      a_reg[i] = v;
+    }
+    const int koff = tap * p.Cin + c0;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ptr[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + koff);
+      b_reg[j] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+    float* a_dst = As + buf * BM * LDS_LD;
+    float* b_dst = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      *reinterpret_cast<f32x4*>(a_dst + (lrow + 32 * i) * LDS_LD + kc * 4) = a_reg[i];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      *reinterpret_cast<f32x4*>(b_dst + (lrow + 32 * j) * LDS_LD + kc * 4) = b_reg[j];
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31;  // fragment row (A: m, B: n)
+  const int fh = lane >> 5;  // K half inside a group of 8
+
+  gather(0);
+  stage(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) gather(kt + 1);  // global loads in flight under the MFMAs below
+
+    const float* a_src = As + cur * BM * LDS_LD + (wm * TM + fr) * LDS_LD + fh * 4;
+    const float* b_src = Bs + cur * BN * LDS_LD + (wn * TN + fr) * LDS_LD + fh * 4;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      f32x4 af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(a_src + i * 32 * LDS_LD + kb * 8);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        bf[j] = *reinterpret_cast<const f32x4*>(b_src + j * 32 * LDS_LD + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+
+    if (kt + 1 < KT) stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (m >= p.M) continue;
+      size_t orow;  // output row (pixel) index for QEA_OUT_NHWC / TBC
+      int cb = 0, ch = 0, cw = 0;
+      if (p.out_mode == QEA_OUT_NHWC) {
+        orow = (size_t)m;
+      } else if (p.out_mode == QEA_OUT_TBC) {
+        const int b = m / p.OW;
+        const int ow = m - b * p.OW;
+        orow = (size_t)ow * p.B + b;
+      } else {
+        cb = m / ohw;
+        const int rem = m - cb * ohw;
+        ch = rem / p.OW;
+        cw = rem - ch * p.OW;
+        orow = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * TN + j * 32 + fr;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r];
+        size_t o;
+        int nb = n;
+        if (p.out_mode == QEA_OUT_CONVT) {
+          const int co_n = p.N >> 2;
+          const int ab = n / co_n;
+          nb = n - ab * co_n;
+          const size_t opix = ((size_t)cb * (2 * p.OH) + 2 * ch + (ab >> 1)) * (2 * p.OW) + 2 * cw + (ab & 1);
+          o = opix * p.ldy + nb;
+        } else {
+          o = orow * p.ldy + n;
+        }
+        if (p.scale) v *= p.scale[n];
+        if (p.bias) v += p.bias[nb];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.mask) {
+          const size_t mo = (p.out_mode == QEA_OUT_CONVT) ? (o / p.ldy) * p.ldmask + nb : orow * p.ldmask + n;
+          v = (p.mask[mo] > 0.f) ? v : 0.f;
+        }
+        if (p.accumulate) v += p.y[o];
+        p.y[o] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch(const ConvArgs& a, hipStream_t s) {
+  ConvArgs p = a;
+  p.m_tiles = qea_cdiv(p.M, BM);
+  p.n_tiles = qea_cdiv(p.N, BN);
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  auto kern = conv_igemm_kernel<BM, BN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const long long grid = (long long)p.m_tiles * p.n_tiles;
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    qea_set_error("qea_conv_igemm: grid %lld out of range", grid);
+    return QEA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
+  return QEA_OK;
+}
+
+}  // namespace
+
+extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
+  QEA_REQUIRE(d && d->x && d->w && d->y, "qea_conv_igemm: null pointer");
+  QEA_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->N > 0,
+              "qea_conv_igemm: non-positive dimension");
+  QEA_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, "qea_conv_igemm: Cin=%d must be a multiple of %d", d->Cin, BK);
+  QEA_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride_h > 0 && d->stride_w > 0, "qea_conv_igemm: bad filter/stride");
+  QEA_REQUIRE(d->ldx >= d->Cin && d->ldx % 4 == 0, "qea_conv_igemm: ldx=%d must be >= Cin and a multiple of 4", d->ldx);
+  QEA_REQUIRE(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "qea_conv_igemm: x/w must be 16-byte aligned");
+  if (d->out_mode == QEA_OUT_TBC) QEA_REQUIRE(d->OH == 1, "qea_conv_igemm: QEA_OUT_TBC needs OH == 1");
+  if (d->out_mode == QEA_OUT_CONVT) {
+    QEA_REQUIRE(d->N % 4 == 0 && d->OH == d->H && d->OW == d->W && d->KH == 1 && d->KW == 1,
+                "qea_conv_igemm: QEA_OUT_CONVT needs a 1x1 GEMM with N = 4*Cout");
+    QEA_REQUIRE(d->ldy >= d->N / 4, "qea_conv_igemm: ldy too small");
+  } else {
+    QEA_REQUIRE(d->ldy >= d->N, "qea_conv_igemm: ldy=%d < N=%d", d->ldy, d->N);
+  }
+  QEA_REQUIRE((long long)d->B * d->H * d->W < 0x7fffffffLL && (long long)d->B * d->OH * d->OW < 0x7fffffffLL,
+              "qea_conv_igemm: pixel count overflows int32");
+
+  ConvArgs a;
+  a.x = d->x; a.w = d->w; a.y = d->y; a.scale = d->scale; a.bias = d->bias; a.mask = d->mask;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.N = d->N;
+  a.KH = d->KH; a.KW = d->KW; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
+  a.ldx = d->ldx; a.ldy = d->ldy; a.ldmask = d->ldmask; a.relu = d->relu; a.accumulate = d->accumulate; a.out_mode = d->out_mode;
+  a.M = d->B * d->OH * d->OW;
+  a.K = d->KH * d->KW * d->Cin;
+  a.m_tiles = a.n_tiles = 0;
+
+  hipStream_t s = (hipStream_t)stream;
+  int tile = d->tile;
+  if (tile == 0) tile = (d->N <= 32) ? 3 : (d->N <= 64) ? 2 : 1;
+  qea_prof_begin(QEA_PROF_CONV_IGEMM, s);
+  int rc;
+  switch (tile) {
+    case 1: rc = launch<128, 128, 2, 2>(a, s); break;
+    case 2: rc = launch<256, 64, 4, 1>(a, s); break;
+    case 3: rc = launch<256, 32, 4, 1>(a, s); break;
+    default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
+  }
+  if (rc != QEA_OK) return rc;
+  qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, 0.0);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}

@@ -1,0 +1,91 @@
+// Library-wide state: last-error string, ABI version, per-kernel-class event timing.
+#include "common.h"
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+namespace {
+thread_local char g_err[512] = "";
+
+struct ProfClass {
+  bool on = false;
+  std::vector<hipEvent_t> start, stop;  // event pool, reused across resets
+  size_t used = 0;
+  double flops = 0.0, bytes = 0.0;
+  bool open = false;
+};
+ProfClass g_prof[QEA_PROF_NCLASS];
+std::mutex g_prof_mu;
+}  // namespace
+
+void qea_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* qea_last_error(void) { return g_err; }
+extern "C" int qea_version(void) { return 1; }
+
+void qea_prof_begin(int klass, hipStream_t s) {
+  ProfClass& pc = g_prof[klass];
+  if (!pc.on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (pc.used == pc.start.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    pc.start.push_back(a);
+    pc.stop.push_back(b);
+  }
+  hipEventRecord(pc.start[pc.used], s);
+  pc.open = true;
+}
+
+void qea_prof_end(int klass, hipStream_t s, double flops, double bytes) {
+  ProfClass& pc = g_prof[klass];
+  if (!pc.on || !pc.open) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEventRecord(pc.stop[pc.used], s);
+  pc.used++;
+  pc.flops += flops;
+  pc.bytes += bytes;
+  pc.open = false;
+}
+
+extern "C" int qea_prof_enable(int klass, int on) {
+  QEA_REQUIRE(klass >= 0 && klass < QEA_PROF_NCLASS, "qea_prof_enable: bad class %d", klass);
+  g_prof[klass].on = on != 0;
+  return QEA_OK;
+}
+
+extern "C" int qea_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& pc : g_prof) {
+    pc.used = 0;
+    pc.flops = pc.bytes = 0.0;
+    pc.open = false;
+  }
+  return QEA_OK;
+}
+
+extern "C" int qea_prof_read(int klass, double* ms, double* flops, double* bytes, int64_t* launches) {
+  QEA_REQUIRE(klass >= 0 && klass < QEA_PROF_NCLASS, "qea_prof_read: bad class %d", klass);
+  ProfClass& pc = g_prof[klass];
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double total = 0.0;
+  for (size_t i = 0; i < pc.used; ++i) {
+    if (hipEventSynchronize(pc.stop[i]) != hipSuccess) {
+      qea_set_error("qea_prof_read: event sync failed");
+      return QEA_ERR_LAUNCH;
+    }
+    float t = 0.f;
+    hipEventElapsedTime(&t, pc.start[i], pc.stop[i]);
+    total += t;
+  }
+  if (ms) *ms = total;
+  if (flops) *flops = pc.flops;
+  if (bytes) *bytes = pc.bytes;
+  if (launches) *launches = (int64_t)pc.used;
+  return QEA_OK;
+}

@@ -1,0 +1,70 @@
+"""HIP implicit-GEMM conv (qea_conv_igemm) vs torch-CPU conv2d on every distinct conv shape
+of the hot path, through the C ABI."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(B, H, W, Cin, Cout, KH, KW, pad, stride=1, relu=False, bias=False, tile=0, seed=0):
+    from qea import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=stride, padding=pad)
+    if relu:
+        ref = ref.relu()
+    OH, OW = ref.shape[2], ref.shape[3]
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    bd = b.cuda() if bias else None
+    y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+    d = _lib.ConvDesc(
+        x=xd.data_ptr(), w=wd.data_ptr(), y=y.data_ptr(), scale=None,
+        bias=bd.data_ptr() if bias else None, mask=None,
+        B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW, N=Cout, KH=KH, KW=KW, pad_h=pad, pad_w=pad,
+        stride_h=stride, stride_w=stride, ldx=Cin, ldy=Cout, ldmask=0, relu=int(relu),
+        accumulate=0, out_mode=0, tile=tile)
+    _lib.check(L.qea_conv_igemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "qea_conv_igemm")
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-5 * max(scale, 1.0), (err, scale)
+
+
+SHAPES = [
+    # (H, W, Cin, Cout)  UNet levels and CRNN backbone
+    (32, 128, 32, 32), (32, 128, 64, 32), (16, 64, 32, 64), (16, 64, 64, 64), (16, 64, 128, 64),
+    (8, 32, 64, 128), (8, 32, 128, 128), (8, 32, 256, 128), (4, 16, 128, 256), (4, 16, 256, 256),
+    (4, 16, 512, 256), (2, 8, 256, 512), (2, 8, 512, 512),
+    (16, 64, 64, 128), (8, 32, 128, 256), (8, 32, 256, 256), (4, 32, 256, 512), (4, 32, 512, 512),
+]
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout", SHAPES)
+def test_conv3x3_shapes(H, W, Cin, Cout):
+    _run(3, H, W, Cin, Cout, 3, 3, 1)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_conv3x3_all_tiles_ragged(tile):
+    # M = 5*7*9 = 315 and N = 40 are not multiples of any tile edge
+    _run(5, 7, 9, 64, 40, 3, 3, 1, relu=True, bias=True, tile=tile)
+
+
+def test_conv7_2x2_pad0():
+    _run(4, 2, 32, 512, 512, 2, 2, 0, bias=True)
+
+
+def test_conv_2x2_stride2():
+    _run(2, 8, 16, 64, 128, 2, 2, 0, stride=2)
+
+
+def test_gemm_1x1():
+    _run(1, 1, 300, 512, 95, 1, 1, 0, bias=True)

@@ -1,0 +1,54 @@
+"""Per-shape timing of qea_conv_igemm at the bench batch (developer tool, GPU box only)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "query-efficient-approx-to-improve-ocr_amd"))
+from qea import _lib  # noqa: E402
+
+SHAPES = [
+    (32, 128, 32, 32), (32, 128, 64, 32), (16, 64, 32, 64), (16, 64, 64, 64), (16, 64, 128, 64),
+    (8, 32, 64, 128), (8, 32, 128, 128), (8, 32, 256, 128), (4, 16, 128, 256), (4, 16, 256, 256),
+    (4, 16, 512, 256), (2, 8, 256, 512), (2, 8, 512, 512),
+    (16, 64, 64, 128), (8, 32, 128, 256), (8, 32, 256, 256), (4, 32, 256, 512), (4, 32, 512, 512),
+]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    tot_t = tot_f = 0.0
+    for (H, W, Cin, Cout) in SHAPES:
+        x = torch.randn(B, H, W, Cin, device="cuda")
+        w = torch.randn(Cout, 3, 3, Cin, device="cuda")
+        y = torch.empty(B, H, W, Cout, device="cuda")
+        for tile in tiles:
+            d = _lib.ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), scale=None, bias=None, mask=None,
+                              B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad_h=1, pad_w=1,
+                              stride_h=1, stride_w=1, ldx=Cin, ldy=Cout, ldmask=0, relu=0, accumulate=0,
+                              out_mode=0, tile=tile)
+            for _ in range(2):
+                _lib.check(L.qea_conv_igemm(C.byref(d), s))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 5
+            e0.record()
+            for _ in range(n):
+                L.qea_conv_igemm(C.byref(d), s)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            fl = 2.0 * B * H * W * Cout * 9 * Cin
+            print(f"H{H:3d} W{W:3d} Cin{Cin:4d} Cout{Cout:4d} tile{tile} {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
+            if tile == tiles[0]:
+                tot_t += ms
+                tot_f += fl
+    print(f"TOTAL {tot_t:.2f} ms  {tot_f / tot_t / 1e9:.1f} TF (first tile choice)")
+
+
+if __name__ == "__main__":
+    main()
