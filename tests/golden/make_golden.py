@@ -1,0 +1,344 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the build
+container (torch 2.10.0+rocm7.0 CPU path, AVX512 host).  The reference never travels to the
+GPU box; only the small .npz/.json files written here do.
+
+    python tests/golden/make_golden.py            # needs /root/reference
+
+Importable reference modules (models.*, selection_utils, tracking_utils, properties) are imported
+as they are.  transform_helper.py and utils.py do not import here (torchvision / Levenshtein /
+unidecode / wandb / optuna are not installed), so the individual definitions on the hot path
+(AddGaussianNoice, pred_to_string, padder, get_text_stack) are compiled from the reference file
+with `ast` and executed unchanged with only `torch` in scope — nothing is stubbed.
+"""
+import ast
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("QEA_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+
+import properties  # noqa: E402  (reference)
+import selection_utils  # noqa: E402  (reference)
+from models.model_crnn import CRNN  # noqa: E402  (reference)
+from models.model_unet import UNet  # noqa: E402  (reference)
+
+from oracle import model_oracle as mo  # noqa: E402  (only for the name-keyed weight fill)
+
+
+def ref_defs(relpath, names):
+    """Compile the named top-level defs/classes of a reference file and return them."""
+    src = open(os.path.join(REF, relpath)).read()
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=body, type_ignores=[]), relpath, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def load_seeded(module, shapes, seed):
+    st = mo.seeded_state(shapes, seed)
+    missing = set(module.state_dict().keys()) ^ set(st.keys())
+    assert not missing, missing
+    module.load_state_dict(st)
+    return module
+
+
+def grad_summary(named_params, prefix, out):
+    for name, p in named_params:
+        g = p.grad.detach().double().flatten()
+        out[f"{prefix}{name}|sum"] = g.sum().item()
+        out[f"{prefix}{name}|abs"] = g.abs().sum().item()
+        out[f"{prefix}{name}|l2"] = g.norm().item()
+        out[f"{prefix}{name}|head"] = g[:16].numpy().copy()
+
+
+def tensor_summary(named, prefix, out):
+    for name, t in named:
+        v = t.detach().double().flatten()
+        out[f"{prefix}{name}|sum"] = v.sum().item()
+        out[f"{prefix}{name}|abs"] = v.abs().sum().item()
+        out[f"{prefix}{name}|head"] = v[:16].numpy().copy()
+
+
+def synth_images(b, seed, h=32, w=128):
+    """POS-style patches: white background, dark strokes, light noise."""
+    g = torch.Generator().manual_seed(seed)
+    m = (torch.rand(b, 1, h, w, generator=g) < 0.12).float()
+    ink = torch.rand(b, 1, h, w, generator=g) * 0.7 + 0.3
+    return (1 - m * ink + 0.02 * torch.randn(b, 1, h, w, generator=g)).clamp(0, 1)
+
+
+def synth_labels(b, seed, lo=1, hi=12):
+    rng = np.random.RandomState(seed)
+    return ["".join(properties.char_set[i] for i in rng.randint(1, 95, rng.randint(lo, hi + 1))) for _ in range(b)]
+
+
+def encode(labels):
+    c2i = {c: i for i, c in enumerate(properties.char_set)}
+    y = torch.tensor([c2i[c] for c in "".join(labels)], dtype=torch.int)
+    return y, torch.tensor([len(l) for l in labels], dtype=torch.int)
+
+
+# --------------------------------------------------------------------------------------------
+def make_unet():
+    out = {}
+    x = synth_images(2, 11)
+    out["x"] = x.numpy()
+    # eval-mode forward (Phase A use, train_nn_patch.py:227,239)
+    net = load_seeded(UNet(), mo.unet_state_shapes(), 1).eval()
+    with torch.no_grad():
+        out["y_eval"] = net(x).numpy()
+    # train-mode forward + backward of scalar*MSE(y, 1) + <y, r>  (Phase B use, :312-329)
+    net = load_seeded(UNet(), mo.unet_state_shapes(), 1).train()
+    y = net(x)
+    r = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+    out["r"] = r.numpy()
+    loss = torch.nn.MSELoss()(y, torch.ones_like(y)) + (y * r).sum() / y.numel()
+    loss.backward()
+    out["y_train"] = y.detach().numpy()
+    out["loss"] = loss.item()
+    grad_summary(net.named_parameters(), "g|", out)
+    tensor_summary(((k, v) for k, v in net.state_dict().items() if mo.is_buffer(k)), "buf|", out)
+    np.savez_compressed(os.path.join(HERE, "unet_b2.npz"), **out)
+    print("unet_b2", loss.item())
+
+
+def make_crnn():
+    out = {}
+    x = synth_images(3, 21).requires_grad_()
+    labels = synth_labels(3, 3)
+    labels[1] = "aa" * 9          # 18 chars with 17 repeats -> needs 35 > 31 frames: infeasible (F3)
+    out["labels"] = np.array(labels)
+    y, ysz = encode(labels)
+    for mode in ("bn_train", "bn_eval"):
+        net = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 2)
+        net.register_backward_hook(net.backward_hook)       # train_nn_patch.py:94
+        net.train()
+        if mode == "bn_eval":                                 # utils.py:113-115 via train_nn_patch.py:314
+            for m in net.modules():
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        x.grad = None
+        lp = net(x)
+        T = lp.shape[0]
+        insz = torch.tensor([T] * 3, dtype=torch.int)
+        per = torch.nn.CTCLoss(reduction="none")(lp, y, insz, ysz)
+        loss = torch.nn.CTCLoss()(lp, y, insz, ysz)
+        loss.backward()
+        out[f"{mode}|lp"] = lp.detach().numpy()
+        out[f"{mode}|nll"] = per.detach().numpy()
+        out[f"{mode}|loss"] = loss.item()
+        out[f"{mode}|dx"] = x.grad.numpy().copy()
+        grad_summary(net.named_parameters(), f"{mode}|g|", out)
+        tensor_summary(((k, v) for k, v in net.state_dict().items() if mo.is_buffer(k)), f"{mode}|buf|", out)
+        print("crnn", mode, loss.item(), per.detach().numpy())
+    out["x"] = x.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "crnn_b3.npz"), **out)
+
+
+def make_ctc():
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    T, N, C = 31, 8, 95
+    lp = (torch.randn(T, N, C, generator=g) * 2).log_softmax(2).requires_grad_()
+    rng = np.random.RandomState(9)
+    tl = [5, 1, 15, 12, 0, 31, 16, 3]
+    tg = [list(rng.randint(1, C, l)) for l in tl]
+    tg[2] = [4, 4, 9, 9, 9, 2, 3, 3, 1, 5, 6, 7, 8, 8, 2]   # 5 repeats: 15 + 5 = 20 <= 31 feasible
+    tg[3] = [7] * 12                                          # 12 + 11 = 23 feasible, all repeats
+    tg[5] = list(rng.randint(1, C, 31))                       # len == T: feasible only if no repeats
+    for i in range(1, 31):
+        if tg[5][i] == tg[5][i - 1]:
+            tg[5][i] = tg[5][i] % (C - 1) + 1
+    tg[6] = [3] * 16                                          # 16 + 15 = 31 -> exactly feasible
+    tg[7] = [0 + 1, 1 + 1, 1 + 1]
+    flat = torch.tensor([c for t in tg for c in t], dtype=torch.int)
+    tls = torch.tensor(tl, dtype=torch.int)
+    ins = torch.full((N,), T, dtype=torch.int)
+    per = torch.nn.CTCLoss(reduction="none")(lp, flat, ins, tls)
+    loss = torch.nn.CTCLoss()(lp, flat, ins, tls)
+    loss.backward()
+    out.update(lp=lp.detach().numpy(), targets=flat.numpy(), target_lengths=tls.numpy(), nll=per.detach().numpy(),
+               loss_mean=loss.item(), grad_mean=lp.grad.numpy().copy())
+    # a second batch with infeasible members (loss = inf, NaN grads before the scrub)
+    lp2 = (torch.randn(T, 4, C, generator=g)).log_softmax(2).requires_grad_()
+    tl2 = [40, 2, 17, 20]
+    tg2 = [list(rng.randint(1, C, 40)), [5, 5], [6] * 17, list(rng.randint(1, C, 20))]
+    flat2 = torch.tensor([c for t in tg2 for c in t], dtype=torch.int)
+    tls2 = torch.tensor(tl2, dtype=torch.int)
+    ins2 = torch.full((4,), T, dtype=torch.int)
+    per2 = torch.nn.CTCLoss(reduction="none")(lp2, flat2, ins2, tls2)
+    loss2 = torch.nn.CTCLoss()(lp2, flat2, ins2, tls2)
+    loss2.backward()
+    out.update(inf_lp=lp2.detach().numpy(), inf_targets=flat2.numpy(), inf_target_lengths=tls2.numpy(),
+               inf_nll=per2.detach().numpy(), inf_loss_mean=loss2.item(), inf_grad_mean=lp2.grad.numpy().copy())
+    np.savez_compressed(os.path.join(HERE, "ctc_cases.npz"), **out)
+    print("ctc", per.detach().numpy(), per2.detach().numpy())
+
+
+def make_topk():
+    cases = []
+    Sampler = selection_utils.datasampler_factory("topKCER")
+    rng = np.random.RandomState(3)
+    real = json.load(open(os.path.join(REF, "cer_data_utils", "pos_dataset_cers.json")))
+    real_items = list(real.items())
+
+    def run(cers, names, k, note):
+        s = Sampler(dict(cers))
+        imgs = torch.arange(len(names)).float().view(-1, 1)
+        sel_imgs, sel_labels, idx = s.query(imgs, list(names), k, list(names))
+        cases.append({"note": note, "names": list(names), "cers": cers, "k": k, "idx": idx.tolist(),
+                      "sel": sel_imgs.view(-1).long().tolist()})
+
+    # tie-free, sizes around the n >= 17 threshold of SURVEY F4 and the bench batch
+    for n in (5, 16, 17, 64, 512):
+        names = [f"s{i}" for i in range(n)]
+        vals = rng.permutation(n).astype(np.float64) / n
+        run({nm: float(v) for nm, v in zip(names, vals)}, names, max(1, math.ceil(n * 0.05)), f"tie-free n={n}")
+    # ties, n <= 16 (torch's small-sort path is stable there)
+    names = [f"t{i}" for i in range(12)]
+    run({nm: float(v) for nm, v in zip(names, [0, 1, 0.5, 1, 0, 0.5, 0.25, 1, 0, 0, 0.5, 0.25])}, names, 5, "ties n=12")
+    # ties at n > 16: value multiset is the contract; index order is build-specific (recorded)
+    names = [f"u{i}" for i in range(40)]
+    vals = rng.choice([0.0, 0.5, 1.0, 1 / 3], 40)
+    run({nm: float(v) for nm, v in zip(names, vals)}, names, 10, "ties n=40 (index order build-specific: torch 2.10.0+rocm7.0 AVX512)")
+    # real POS CER slices (cer_data_utils/pos_dataset_cers.json), with a name missing from the dict
+    for start, n in ((0, 20), (1000, 24), (5000, 64)):
+        sl = real_items[start:start + n]
+        names = [k for k, _ in sl]
+        run({k: float(v) for k, v in sl}, names, max(1, math.ceil(n * 0.5)), f"real slice {start}:{start + n}")
+    sl = real_items[200:216]
+    names = [k for k, _ in sl]
+    d = {k: float(v) for k, v in sl}
+    del d[names[3]]
+    s = Sampler(d)
+    imgs = torch.arange(16).float().view(-1, 1)
+    _, _, idx = s.query(imgs, names, 4, names)
+    cases.append({"note": "name missing from dict (indices address the compacted list)", "names": names, "cers": d,
+                  "k": 4, "idx": idx.tolist(), "sel": None})
+    json.dump({"torch": torch.__version__, "cases": cases}, open(os.path.join(HERE, "topk_cases.json"), "w"))
+    print("topk", len(cases))
+
+
+def make_helpers():
+    out = {}
+    (Noise,) = ref_defs("transform_helper.py", ["AddGaussianNoice"])
+    pred_to_string, padder, get_text_stack = ref_defs("utils.py", ["pred_to_string", "padder", "get_text_stack"])
+    img = synth_images(1, 31)[0]
+    for stochastic in (False, True):
+        torch.manual_seed(123)
+        o, n = Noise(std=5, is_stochastic=stochastic, return_noise=True)(img.clone())
+        out[f"jit{int(stochastic)}|out"] = o.numpy()
+        out[f"jit{int(stochastic)}|noise"] = n.numpy()
+    out["jit|img"] = img.numpy()
+    torch.manual_seed(123)
+    o, n = Noise(std=3, return_noise=True)(img.clone(), noise_coef=0.5)
+    out["jitc|out"], out["jitc|noise"] = o.numpy(), n.numpy()
+    # greedy decode
+    g = torch.Generator().manual_seed(17)
+    scores = torch.randn(31, 6, 95, generator=g)
+    scores[:, :, 0] += 2.5      # plenty of blanks
+    scores[3:6, 0, :] = scores[3:4, 0, :]   # repeats
+    i2c = {i: c for i, c in enumerate(properties.char_set)}
+    out["dec|scores"] = scores.numpy()
+    out["dec|strings"] = np.array(pred_to_string(scores, [""] * 6, i2c))
+    # crop + pad
+    page = torch.rand(1, 60, 200, generator=g)
+    boxes = [dict(label="ab", x_min=3, y_min=4, x_max=100, y_max=30), dict(label="c", x_min=150, y_min=0, x_max=199, y_max=31),
+             dict(label="d", x_min=10, y_min=20, x_max=137, y_max=51), dict(label="e", x_min=0, y_min=0, x_max=1, y_max=1)]
+    stack, labels = get_text_stack(page, boxes, (32, 128))
+    out["crop|page"] = page.numpy()
+    out["crop|boxes"] = np.array([[b["x_min"], b["y_min"], b["x_max"], b["y_max"]] for b in boxes])
+    out["crop|stack"] = stack.numpy()
+    np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
+    print("helpers", out["dec|strings"])
+
+
+def make_step():
+    """One full train_nn_area-style step (Phase A then Phase B, train_nn_area.py:212-287) on the
+    reference modules: TopKCER pick, 2 jitter replicas with explicit seeded noise, a fixed label
+    oracle in place of the OCR engine, CTC, Adam(CRNN); then UNet(train)->CRNN(BN eval)->
+    CTC+MSE->Adam(UNet)."""
+    out = {}
+    B, inner, prop, std = 4, 2, 0.5, 5
+    x = synth_images(B, 41)
+    labels = synth_labels(B, 43, 2, 8)
+    names = [f"img{i}.png" for i in range(B)]
+    cers = {n: c for n, c in zip(names, [0.25, 0.8, 0.0, 0.5])}
+    prep = load_seeded(UNet(), mo.unet_state_shapes(), 3)
+    crnn = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 4)
+    crnn.register_backward_hook(crnn.backward_hook)
+    opt_c = torch.optim.Adam(crnn.parameters(), lr=1e-4, weight_decay=0)
+    opt_p = torch.optim.Adam(prep.parameters(), lr=5e-5, weight_decay=0)
+    ctc = torch.nn.CTCLoss()
+    sampler = selection_utils.datasampler_factory("topKCER")(dict(cers))
+    # ---- Phase A
+    crnn.train(); prep.eval(); prep.zero_grad(); crnn.zero_grad()
+    preds_all = prep(x)
+    k = max(1, math.ceil(B * (1 - prop)))
+    preds, labels_sel, idx = sampler.query(preds_all, labels, k, names)
+    preds = preds.detach()
+    out["A|idx"] = idx.numpy()
+    g = torch.Generator().manual_seed(45)
+    losses = []
+    for i in range(inner):
+        noise = torch.randn(preds.shape, generator=g) * (std / 100.0)
+        noisy = (preds - noise).clamp(0, 1)
+        out[f"A|noise{i}"] = noise.numpy()
+        ocr_labels = [l[::-1] for l in labels_sel]     # the "OCR" of this fixture: reversed GT
+        lp = crnn(noisy)
+        y, ysz = encode(ocr_labels)
+        loss = ctc(lp, y, torch.tensor([lp.shape[0]] * len(ocr_labels), dtype=torch.int), ysz)
+        losses.append(loss.item())
+    loss.backward()                                      # area trainer: last replica only (F6)
+    out["A|losses"] = np.array(losses)
+    grad_summary(crnn.named_parameters(), "A|g|", out)
+    opt_c.step()
+    tensor_summary(crnn.state_dict().items(), "A|crnn|", out)
+    # ---- Phase B starts from a freshly seeded CRNN (seed 6), NOT from the post-Phase-A weights:
+    # Adam's first step is lr*sign(g) wherever |g| is rounding noise, so the post-step weights of
+    # the reference itself differ by up to 1.6e-4 between a 1-thread and an 8-thread run, and that
+    # moves individual Phase-B UNet gradients by 1-2 % (measured here) — a chained A->B fixture
+    # cannot be pinned to 1e-4.  The A-then-B ordering is pinned by the post-step
+    # summaries above; the Phase-B arithmetic by the block below.
+    crnn = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 6)
+    crnn.register_backward_hook(crnn.backward_hook)
+    # ---- Phase B
+    prep.train(); crnn.train()
+    for m in crnn.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    prep.zero_grad(); crnn.zero_grad()
+    img = prep(x)
+    lp = crnn(img)
+    y, ysz = encode(labels)
+    lossB = ctc(lp, y, torch.tensor([lp.shape[0]] * B, dtype=torch.int), ysz) + torch.nn.MSELoss()(img, torch.ones_like(img)) * 1.0
+    lossB.backward()
+    opt_p.step()
+    out["B|loss"] = lossB.item()
+    out["B|img"] = img.detach().numpy()
+    out["B|lp"] = lp.detach().numpy()
+    grad_summary(prep.named_parameters(), "B|g|prep|", out)
+    grad_summary(crnn.named_parameters(), "B|g|crnn|", out)
+    tensor_summary(prep.state_dict().items(), "B|prep|", out)
+    out["x"] = x.numpy()
+    out["labels"] = np.array(labels)
+    out["names"] = np.array(names)
+    out["cers"] = np.array([cers[n] for n in names])
+    np.savez_compressed(os.path.join(HERE, "step_area_b4.npz"), **out)
+    print("step", losses, lossB.item(), idx)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["unet", "crnn", "ctc", "topk", "helpers", "step"]
+    for w in which:
+        globals()["make_" + w]()
