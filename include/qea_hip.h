@@ -85,6 +85,32 @@ typedef struct qea_conv_desc {
 
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Weight gradient on the fp32 matrix cores (reduction over pixels, split over blocks,
+ * order-fixed second pass: bit-reproducible).
+ *   dw[r][kh][kw][c] (+)= sum_{b,ph,pw} p[b,ph,pw][r] * q[b, ph*sh+kh-pad_h, pw*sw+kw-pad_w][c]
+ * nn.Conv2d weight gradient (autograd of models/model_unet.py:78-109, model_crnn.py:38-45):
+ *   p = dY, q = X.  nn.ConvTranspose2d (model_unet.py:25-41): p = X, q = dY, KH=KW=2,
+ *   stride 2, pad 0 -> dw in [Cin][2][2][Cout].  nn.Linear / nn.LSTM weights: KH=KW=1.
+ * R, C, ldp, ldq multiples of 4.  Workspace: qea_conv_wgrad_workspace_bytes(d).
+ * ---------------------------------------------------------------------------------- */
+typedef struct qea_wgrad_desc {
+  const float* p;   /* [B*PH*PW][ldp], R channels used                                    */
+  const float* q;   /* NHWC image [B,QH,QW] with pixel stride ldq, C channels used        */
+  float* dw;        /* [R][KH*KW][C]                                                      */
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t B, PH, PW, QH, QW, R, C;
+  int32_t KH, KW, pad_h, pad_w, stride_h, stride_w;
+  int32_t ldp, ldq;
+  int32_t accumulate; /* dw += result                                                     */
+  int32_t splits;     /* 0 = auto                                                         */
+  int32_t tile;       /* 0 = auto                                                         */
+} qea_wgrad_desc;
+
+size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d);
+int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,322 @@
+// Weight gradient of the implicit-GEMM convolution on the fp32 matrix cores:
+//
+//   dW[r][tap][c] = sum_{m = (b,ph,pw)}  P[m][r] * Q[b, ph*sh + kh - pad_h, pw*sw + kw - pad_w][c]
+//
+// conv2d:          P = dY (r = output channel), Q = X (c = input channel)
+// convTranspose2d: P = X  (r = input channel),  Q = dY (c = output channel), stride 2, pad 0
+// linear / LSTM:   KH = KW = 1
+//
+// The reduction index is the pixel m, the slow dimension of both operands, so tiles are
+// staged pixel-major ([32 pixels][channels]) and MFMA fragments are read column-wise with
+// ds_read_b32 (lane l: channel l&31 of pixel 2s + (l>>5) at MFMA step s).  The pixel range is
+// split over blockIdx.y; partial results go to a workspace slab per split and a second,
+// order-fixed pass sums them (bit-reproducible, no float atomics).
+//
+// Roofline: MFMA-bound for wide layers (2*M*R*taps*C flops), L2/HBM-leaning for the 32/64-
+// channel UNet levels where each pixel carries only 2*R*C*taps flops per (R+C)*4 bytes.
+#include "common.h"
+
+namespace {
+
+struct WgArgs {
+  const float* p;
+  const float* q;
+  float* out;  // workspace slab base (splits > 1) or dW
+  int B, PH, PW, QH, QW, R, C, KH, KW, pad_h, pad_w, stride_h, stride_w, ldp, ldq;
+  int M, chunk, splits, accumulate;
+  int r_tiles, c_tiles, tiles;  // tiles = r_tiles * taps * c_tiles
+  long long slab;               // floats per split slab (R*taps*C)
+};
+
+constexpr int BKP = 32;  // pixels per stage
+
+template <int BR, int BC, int WR, int WC, int WK>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
+  constexpr int TR = BR / WR, TCc = BC / WC;
+  constexpr int MI = TR / 32, NJ = TCc / 32;
+  constexpr int P_LD = BR / 32;  // float4 loads per thread per stage (P); 32*BR/4/256
+  constexpr int Q_LD = BC / 32;
+  constexpr int STEPS = (BKP / 2) / WK;  // MFMA k-steps per wave per stage
+  static_assert(WR * WC * WK == 4, "4 waves");
+  constexpr int STAGE_FLOATS = BKP * (BR + BC);
+  constexpr int RED_FLOATS = (WK > 1) ? WK * BR * BC : 0;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ps = smem;                 // [2][BKP][BR]
+  float* Qs = smem + 2 * BKP * BR;  // [2][BKP][BC]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WR * WC);
+  const int wrc = wave % (WR * WC);
+  const int wr = wrc / WC, wc = wrc % WC;
+
+  // tile decode: all tiles of one split are consecutive block ids (-> shared L2 lines)
+  const int split = blockIdx.y;
+  const int tile = blockIdx.x;
+  const int taps = a.KH * a.KW;
+  const int c_tile = tile % a.c_tiles;
+  const int tap = (tile / a.c_tiles) % taps;
+  const int r_tile = tile / (a.c_tiles * taps);
+  const int r0 = r_tile * BR, c0 = c_tile * BC;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+
+  const int m_begin = split * a.chunk;
+  const int m_end = min(a.M, m_begin + a.chunk);
+  const int phw = a.PH * a.PW;
+
+  f32x4 p_reg[P_LD], q_reg[Q_LD];
+  auto gather = [&](int mbase) {
+#pragma unroll
+    for (int i = 0; i < P_LD; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (BR / 4), c4 = f % (BR / 4);
+      const int m = mbase + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end && r0 + c4 * 4 < a.R) v = *reinterpret_cast<const f32x4*>(a.p + (size_t)m * a.ldp + r0 + c4 * 4);
+      p_reg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Q_LD; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (BC / 4), c4 = f % (BC / 4);
+      const int m = mbase + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end && c0 + c4 * 4 < a.C) {
+        const int b = m / phw;
+        const int rem = m - b * phw;
+        const int ph = rem / a.PW;
+        const int pw = rem - ph * a.PW;
+        const int qh = ph * a.stride_h + kh - a.pad_h;
+        const int qw = pw * a.stride_w + kw - a.pad_w;
+        if ((unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW)
+          v = *reinterpret_cast<const f32x4*>(a.q + ((size_t)(b * a.QH + qh) * a.QW + qw) * a.ldq + c0 + c4 * 4);
+      }
+      q_reg[i] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+    float* pd = Ps + buf * BKP * BR;
+    float* qd = Qs + buf * BKP * BC;
+#pragma unroll
+    for (int i = 0; i < P_LD; ++i) *reinterpret_cast<f32x4*>(pd + (tid + 256 * i) * 4) = p_reg[i];
+#pragma unroll
+    for (int i = 0; i < Q_LD; ++i) *reinterpret_cast<f32x4*>(qd + (tid + 256 * i) * 4) = q_reg[i];
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nstage = (m_end > m_begin) ? (m_end - m_begin + BKP - 1) / BKP : 0;
+
+  if (nstage > 0) {
+    gather(m_begin);
+    stage(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nstage) gather(m_begin + (st + 1) * BKP);
+    const float* ps = Ps + cur * BKP * BR + (wk * (BKP / WK) + fh) * BR + wr * TR + fr;
+    const float* qs = Qs + cur * BKP * BC + (wk * (BKP / WK) + fh) * BC + wc * TCc + fr;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      float af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = ps[s * 2 * BR + i * 32];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = qs[s * 2 * BC + j * 32];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nstage) stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- cross-wave reduction of the K-split (through LDS), then store ----
+  float* outp = a.out + (size_t)split * a.slab;
+  const int ktot = taps * a.C;
+  if constexpr (WK > 1) {
+    static_assert(RED_FLOATS <= 2 * STAGE_FLOATS || true, "");
+    float* red = smem;  // [WK][BR][BC]   (staging buffers are dead after the last barrier)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = wr * TR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const int cc = wc * TCc + j * 32 + fr;
+          red[(wk * BR + rr) * BC + cc] = acc[i][j][r];
+        }
+    __syncthreads();
+    for (int e = tid; e < BR * BC; e += 256) {
+      const int rr = e / BC, cc = e - rr * BC;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < WK; ++k) v += red[(k * BR + rr) * BC + cc];
+      if (r0 + rr < a.R && c0 + cc < a.C) {
+        const size_t o = (size_t)(r0 + rr) * ktot + tap * a.C + c0 + cc;
+        if (a.accumulate) v += outp[o];
+        outp[o] = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = r0 + wr * TR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const int cc = c0 + wc * TCc + j * 32 + fr;
+          if (rr < a.R && cc < a.C) {
+            const size_t o = (size_t)rr * ktot + tap * a.C + cc;
+            float v = acc[i][j][r];
+            if (a.accumulate) v += outp[o];
+            outp[o] = v;
+          }
+        }
+  }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n4, int splits,
+                                     long long slab4, int accumulate) {
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(ws);
+  f32x4* d4 = reinterpret_cast<f32x4*>(dw);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 s = w4[i];
+    for (int k = 1; k < splits; ++k) s += w4[i + k * slab4];
+    if (accumulate) s += d4[i];
+    d4[i] = s;
+  }
+}
+
+struct Plan {
+  int tile;  // 1: 128x128  2: 64x64 (K-split)  3: 32x32 (K-split)  4: 32x64  5: 64x32
+  int br, bc;
+  int splits, chunk, tiles, r_tiles, c_tiles;
+};
+
+Plan make_plan(const qea_wgrad_desc* d) {
+  Plan p;
+  const int R = d->R, C = d->C;
+  int tile = d->tile;
+  if (tile == 0) {
+    if (R >= 128 && C >= 128) tile = 1;
+    else if (R <= 32 && C <= 32) tile = 3;
+    else if (R <= 32) tile = 4;
+    else if (C <= 32) tile = 5;
+    else tile = 2;
+  }
+  p.tile = tile;
+  switch (tile) {
+    case 1: p.br = 128; p.bc = 128; break;
+    case 2: p.br = 64; p.bc = 64; break;
+    case 3: p.br = 32; p.bc = 32; break;
+    case 4: p.br = 32; p.bc = 64; break;
+    default: p.br = 64; p.bc = 32; break;
+  }
+  p.r_tiles = qea_cdiv(R, p.br);
+  p.c_tiles = qea_cdiv(C, p.bc);
+  p.tiles = p.r_tiles * p.c_tiles * d->KH * d->KW;
+  const long long M = (long long)d->B * d->PH * d->PW;
+  int splits = d->splits;
+  if (splits <= 0) {
+    splits = (int)((2048 + p.tiles - 1) / p.tiles);
+    const long long max_by_m = (M + 4 * BKP - 1) / (4 * BKP);  // at least 4 stages per split
+    if (splits > max_by_m) splits = (int)max_by_m;
+    if (splits < 1) splits = 1;
+    if (splits > 4096) splits = 4096;
+  }
+  long long chunk = (M + splits - 1) / splits;
+  chunk = (chunk + BKP - 1) / BKP * BKP;
+  p.chunk = (int)chunk;
+  p.splits = (int)((M + chunk - 1) / chunk);
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+template <int BR, int BC, int WR, int WC, int WK>
+void launch(const WgArgs& a, hipStream_t s) {
+  size_t lds = (size_t)2 * BKP * (BR + BC) * sizeof(float);
+  const size_t red = (WK > 1) ? (size_t)WK * BR * BC * sizeof(float) : 0;
+  if (red > lds) lds = red;
+  auto kern = wgrad_kernel<BR, BC, WR, WC, WK>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles, a.splits), dim3(256), lds, s, a);
+}
+
+int validate(const qea_wgrad_desc* d, const char* who) {
+  QEA_REQUIRE(d && d->p && d->q && d->dw, "%s: null pointer", who);
+  QEA_REQUIRE(d->B > 0 && d->PH > 0 && d->PW > 0 && d->QH > 0 && d->QW > 0 && d->R > 0 && d->C > 0, "%s: bad dims", who);
+  QEA_REQUIRE(d->R % 4 == 0 && d->C % 4 == 0, "%s: R=%d and C=%d must be multiples of 4", who, d->R, d->C);
+  QEA_REQUIRE(d->ldp % 4 == 0 && d->ldq % 4 == 0 && d->ldp >= d->R && d->ldq >= d->C, "%s: bad ldp/ldq", who);
+  QEA_REQUIRE(((uintptr_t)d->p & 15) == 0 && ((uintptr_t)d->q & 15) == 0 && ((uintptr_t)d->dw & 15) == 0, "%s: 16-byte alignment", who);
+  QEA_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride_h > 0 && d->stride_w > 0, "%s: bad filter", who);
+  QEA_REQUIRE((long long)d->B * d->PH * d->PW < 0x7fffffffLL && (long long)d->B * d->QH * d->QW < 0x7fffffffLL, "%s: pixel count overflows int32", who);
+  return QEA_OK;
+}
+
+}  // namespace
+
+extern "C" size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d) {
+  if (!d || d->R <= 0 || d->C <= 0 || d->B <= 0) return 0;
+  const Plan p = make_plan(d);
+  if (p.splits <= 1) return 0;
+  return (size_t)p.splits * d->R * d->KH * d->KW * d->C * sizeof(float);
+}
+
+extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
+  int rc = validate(d, "qea_conv_wgrad");
+  if (rc != QEA_OK) return rc;
+  const Plan p = make_plan(d);
+  const size_t need = (p.splits > 1) ? (size_t)p.splits * d->R * d->KH * d->KW * d->C * sizeof(float) : 0;
+  QEA_REQUIRE(need == 0 || (d->workspace && d->workspace_bytes >= need && ((uintptr_t)d->workspace & 15) == 0),
+              "qea_conv_wgrad: workspace of %zu bytes required, %zu given", need, (size_t)d->workspace_bytes);
+
+  WgArgs a;
+  a.p = d->p; a.q = d->q;
+  a.B = d->B; a.PH = d->PH; a.PW = d->PW; a.QH = d->QH; a.QW = d->QW; a.R = d->R; a.C = d->C;
+  a.KH = d->KH; a.KW = d->KW; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
+  a.ldp = d->ldp; a.ldq = d->ldq;
+  a.M = d->B * d->PH * d->PW;
+  a.chunk = p.chunk; a.splits = p.splits;
+  a.r_tiles = p.r_tiles; a.c_tiles = p.c_tiles; a.tiles = p.tiles;
+  a.slab = (long long)d->R * d->KH * d->KW * d->C;
+  a.out = (p.splits > 1) ? (float*)d->workspace : d->dw;
+  a.accumulate = (p.splits > 1) ? 0 : d->accumulate;
+
+  hipStream_t s = (hipStream_t)stream;
+  qea_prof_begin(QEA_PROF_CONV_WGRAD, s);
+  switch (p.tile) {
+    case 1: launch<128, 128, 2, 2, 1>(a, s); break;
+    case 2: launch<64, 64, 1, 1, 4>(a, s); break;
+    case 3: launch<32, 32, 1, 1, 4>(a, s); break;
+    case 4: launch<32, 64, 1, 1, 4>(a, s); break;
+    case 5: launch<64, 32, 1, 1, 4>(a, s); break;
+    default: qea_set_error("qea_conv_wgrad: unknown tile %d", p.tile); return QEA_ERR_INVALID;
+  }
+  if (p.splits > 1) {
+    const long long n4 = a.slab / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)d->workspace, d->dw, n4, p.splits,
+                       a.slab / 4, d->accumulate);
+  }
+  qea_prof_end(QEA_PROF_CONV_WGRAD, s, 2.0 * a.M * (double)a.slab, 0.0);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}

@@ -52,6 +52,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("p", _fp), ("q", _fp), ("dw", _fp), ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+        ("B", _i32), ("PH", _i32), ("PW", _i32), ("QH", _i32), ("QW", _i32), ("R", _i32), ("C", _i32),
+        ("KH", _i32), ("KW", _i32), ("pad_h", _i32), ("pad_w", _i32), ("stride_h", _i32), ("stride_w", _i32),
+        ("ldp", _i32), ("ldq", _i32), ("accumulate", _i32), ("splits", _i32), ("tile", _i32),
+    ]
+
+
 def _declare(L):
     L.qea_version.restype = C.c_int
     L.qea_last_error.restype = C.c_char_p
@@ -59,3 +68,6 @@ def _declare(L):
     L.qea_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.qea_conv_igemm.argtypes = [C.POINTER(ConvDesc), _fp]
+    L.qea_conv_wgrad.argtypes = [C.POINTER(WgradDesc), _fp]
+    L.qea_conv_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
+    L.qea_conv_wgrad_workspace_bytes.restype = C.c_size_t

@@ -1,0 +1,75 @@
+"""HIP weight-gradient kernel (qea_conv_wgrad) vs torch-CPU autograd, through the C ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_case(B, H, W, Cin, Cout, K=3, pad=1, tile=0, splits=0, seed=0, accumulate=False):
+    from qea import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g).double()
+    w = torch.zeros(Cout, Cin, K, K, dtype=torch.double, requires_grad=True)
+    y = F.conv2d(x, w, padding=pad)
+    dy = torch.randn(y.shape, generator=g).double()
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).contiguous()          # [Cout][kh][kw][Cin]
+    OH, OW = y.shape[2], y.shape[3]
+    xd = x.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dw = torch.full(ref.shape, 0.5 if accumulate else float("nan"), device="cuda")
+    ops.conv_wgrad(dyd, xd, dw, B=B, PH=OH, PW=OW, QH=H, QW=W, R=Cout, Cc=Cin, KH=K, KW=K, pad=(pad, pad),
+                   ldp=Cout, ldq=Cin, accumulate=accumulate, tile=tile, splits=splits)
+    torch.cuda.synchronize()
+    got = dw.cpu().double() - (0.5 if accumulate else 0.0)
+    err = (got - ref).abs().max().item()
+    assert err <= 3e-5 * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout", [(32, 128, 32, 32), (32, 128, 64, 32), (16, 64, 32, 64), (16, 64, 64, 64),
+                                          (8, 32, 128, 128), (8, 32, 256, 128), (4, 16, 128, 256), (2, 8, 512, 512),
+                                          (4, 32, 256, 512)])
+def test_wgrad_conv3x3(H, W, Cin, Cout):
+    _conv_case(2, H, W, Cin, Cout)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_wgrad_tiles_ragged_and_splits(tile):
+    _conv_case(3, 5, 7, 36, 44, tile=tile, splits=1)
+    _conv_case(3, 5, 7, 36, 44, tile=tile, splits=3, accumulate=True)
+
+
+def test_wgrad_conv7_2x2():
+    _conv_case(3, 2, 32, 512, 512, K=2, pad=0)
+
+
+def test_wgrad_convtranspose():
+    from qea import ops
+    g = torch.Generator().manual_seed(1)
+    B, H, W, Ci, Co = 2, 4, 16, 64, 32
+    x = torch.randn(B, Ci, H, W, generator=g).double()
+    w = torch.zeros(Ci, Co, 2, 2, dtype=torch.double, requires_grad=True)
+    y = F.conv_transpose2d(x, w, stride=2)
+    dy = torch.randn(y.shape, generator=g).double()
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).contiguous()          # [Cin][a][b][Cout]
+    xd = x.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dw = torch.empty(ref.shape, device="cuda")
+    ops.conv_wgrad(xd, dyd, dw, B=B, PH=H, PW=W, QH=2 * H, QW=2 * W, R=Ci, Cc=Co, KH=2, KW=2, stride=(2, 2), ldp=Ci, ldq=Co)
+    torch.cuda.synchronize()
+    assert (dw.cpu().double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
+def test_wgrad_linear():
+    from qea import ops
+    g = torch.Generator().manual_seed(2)
+    M, K, N = 31 * 7, 512, 96
+    x = torch.randn(M, K, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    ref = dy.double().t() @ x.double()
+    dw = torch.empty(N, K, device="cuda")
+    ops.conv_wgrad(dy.cuda(), x.cuda(), dw, B=1, PH=1, PW=M, QH=1, QW=M, R=N, Cc=K, KH=1, KW=1, ldp=N, ldq=K)
+    torch.cuda.synchronize()
+    assert (dw.cpu().double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
