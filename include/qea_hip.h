@@ -111,6 +111,142 @@ typedef struct qea_wgrad_desc {
 size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d);
 int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * BatchNorm2d over NHWC rows [M = B*H*W][C] (nn.BatchNorm2d at models/model_unet.py:92,105 and
+ * models/model_crnn.py:42,44; mode policy train_nn_patch.py:226-227,312-314, utils.py:113-115).
+ * Statistics are accumulated in fp64.  a = y*scale + shift (+ReLU) with
+ * scale = gamma*invstd, shift = beta - mean*scale.
+ * qea_bn_train_stats : batch mean / biased var -> mean, invstd, scale, shift; running stats
+ *                      updated in place with momentum and the UNBIASED variance.
+ * qea_bn_eval_coeff  : the same four vectors from the running statistics (conv_bias, if given,
+ *                      is folded into shift).
+ * qea_bn_bwd         : dz = da * (a > 0) [a may be NULL: no ReLU]; dgamma = sum dz*xhat,
+ *                      dbeta = sum dz; training: dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)),
+ *                      eval: dy = scale*dz.  dy may alias da.
+ * Workspace for stats / bwd / colsum: qea_colreduce_workspace_bytes(M, C).
+ * ---------------------------------------------------------------------------------- */
+size_t qea_colreduce_workspace_bytes(int64_t M, int32_t C);
+int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
+                       float* invstd_out, float* scale_out, float* shift_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, const float* conv_bias, float* mean_out,
+                      float* invstd_out, float* scale_out, float* shift_out, void* stream);
+int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, int64_t M, int32_t C, const float* scale,
+                 const float* shift, int32_t relu, void* stream);
+int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* y, int32_t ldy, int64_t M,
+               int32_t C, const float* gamma, const float* mean, const float* invstd, int32_t training,
+               float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy, int32_t lddy,
+               void* workspace, size_t workspace_bytes, void* stream);
+/* out[c] (+)= sum_m x[m][c]  — conv / linear / LSTM bias gradients */
+int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, float* out, int32_t accumulate, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/* Max-pool, window == stride (nn.MaxPool2d(2,2) model_unet.py:14-20; fn.max_pool2d (2,2)/(2,1)
+ * model_crnn.py:48-54).  First maximum in (kh,kw) scan order wins, as ATen.  bwd recomputes the
+ * arg-max from x; relu_mask additionally zeroes the gradient where the maximum is <= 0 (pool of
+ * a ReLU output); accumulate: dx += (UNet skip connections). */
+int qea_maxpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C,
+                    int32_t kh, int32_t kw, void* stream);
+int qea_maxpool_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B,
+                    int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t relu_mask, int32_t accumulate,
+                    void* stream);
+
+/* Filter re-layouts for the gradient GEMMs (run once per optimiser step):
+ * out[c][r] = in[r][c];  wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]. */
+int qea_transpose2d(const float* in, float* out, int32_t R, int32_t Cc, void* stream);
+int qea_filter_flip_transpose(const float* w, float* wt, int32_t Co, int32_t Ci, int32_t KH, int32_t KW, void* stream);
+
+/* 3x3 pad-1 convolution with ONE input channel (UNet enc1conv1 model_unet.py:13; CRNN conv1
+ * model_crnn.py:37,48): x [B,H,W], w [Co][9], y NHWC.  wgrad also yields the bias gradient
+ * (db may be NULL); dgrad: dx[B,H,W] (+)= sum_{tap,co} dy * w. */
+int qea_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int32_t ldy, int32_t B, int32_t H,
+                    int32_t W, int32_t Co, int32_t relu, void* stream);
+size_t qea_conv_c1_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Co);
+int qea_conv_c1_wgrad(const float* x, const float* dy, int32_t lddy, float* dw, float* db, int32_t B, int32_t H,
+                      int32_t W, int32_t Co, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int qea_conv_c1_dgrad(const float* dy, int32_t lddy, const float* w, float* dx, int32_t B, int32_t H, int32_t W,
+                      int32_t Co, int32_t accumulate, void* stream);
+
+/* UNet head: y[m] = sigmoid(<x[m,:], w> + b)  (nn.Conv2d 1x1 + torch.sigmoid, model_unet.py:45,76)
+ * bwd: dz = dyy*y*(1-y); dx = dz*w; dw (+)= sum dz*x; db (+)= sum dz. */
+int qea_head_fwd(const float* x, int32_t ldx, const float* w, const float* b, float* y, int64_t M, int32_t C,
+                 void* stream);
+size_t qea_head_bwd_workspace_bytes(int64_t M, int32_t C);
+int qea_head_bwd(const float* x, int32_t ldx, const float* y, const float* dyy, const float* w, float* dx,
+                 int32_t lddx, float* dw, float* db, int32_t accumulate, int64_t M, int32_t C, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * One bidirectional LSTM layer, hidden 256 (nn.LSTM(512,256,2,bidirectional=True),
+ * models/model_crnn.py:9,19; gate order i,f,g,o; zero initial state).
+ * Buffers (seq-first, both directions side by side):
+ *   gates [T][B][2][4][256]  in: x*W_ih^T + b_ih + b_hh (from qea_conv_igemm), out: activations
+ *   c     [T][B][2][256], y [T][B][2][256] (= the layer output)
+ * qea_lstm_pack_whh re-orders one direction's W_hh [1024][256] into per-lane MFMA fragment
+ * order for the forward (h*W_hh^T) and backward (dgates*W_hh) step GEMMs; the two directions'
+ * packed copies must be contiguous ([2][1024*256]).
+ * qea_lstm_layer_bwd turns `gates` in place into pre-activation gate gradients given dy;
+ * dX, dW_ih, dW_hh, db then follow from qea_conv_igemm / qea_conv_wgrad / qea_colsum.
+ * ---------------------------------------------------------------------------------- */
+int qea_lstm_pack_whh(const float* w_hh, float* packed_fwd, float* packed_bwd, void* stream);
+int qea_lstm_layer_fwd(float* gates, float* c, float* y, const float* packed_fwd, int32_t T, int32_t B, void* stream);
+int qea_lstm_layer_bwd(float* gates, const float* c, const float* dy, const float* packed_bwd, float* dc_scratch,
+                       int32_t T, int32_t B, void* stream);
+
+/* log_softmax over the last dim (fn.log_softmax(.., 2), model_crnn.py:20) and its backward
+ * dx = g - exp(lp)*sum(g), with the reference's NaN scrub (CRNN.backward_hook,
+ * model_crnn.py:30-32, registered at train_nn_patch.py:94) when nan_scrub != 0; columns
+ * [C, Cpad) of dx are zeroed. */
+int qea_log_softmax_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int64_t M, int32_t C, void* stream);
+int qea_log_softmax_bwd(const float* g, int32_t ldg, const float* lp, int32_t ldlp, float* dx, int32_t lddx, int64_t M,
+                        int32_t C, int32_t Cpad, int32_t nan_scrub, void* stream);
+
+/* CTC loss (torch.nn.CTCLoss, blank 0, zero_infinity=False; train_nn_patch.py:143,178,294,
+ * train_nn_area.py:146-147,265).  lp element (t,n,c) at t*ld_t + n*ld_n + c.  targets:
+ * concatenated int32 (device), target_offsets[n] = start of sample n.  reduction 1 = 'mean'
+ * (mean_n nll_n/max(len_n,1)), 0 = 'none' (loss = sum, nll[] per sample).  grad (may be NULL)
+ * = d(reduced loss * grad_scale)/d lp exactly as ATen forms it (NaN for infeasible samples).
+ * S_max >= 2*max(target_len)+1, <= 256. */
+size_t qea_ctc_workspace_bytes(int32_t T, int32_t N, int32_t S_max);
+int qea_ctc_loss(const float* lp, int32_t ld_t, int32_t ld_n, const int32_t* targets, const int64_t* target_offsets,
+                 const int32_t* input_lengths, const int32_t* target_lengths, int32_t T, int32_t N, int32_t C,
+                 int32_t blank, int32_t S_max, int32_t reduction, float grad_scale, float* nll, float* loss,
+                 float* grad, int32_t gld_t, int32_t gld_n, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam step over one flat fp32 buffer (train_nn_patch.py:146-152,308-309,343-345):
+ * g' = g*grad_scale + wd*p; m,v update; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
+int qea_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* AddGaussianNoice (transform_helper.py:33-45) for R replicas of K images fused into the batch
+ * dim: out[r*K+k] = clamp(img[k] - coef*sigma[r*K+k]*N(0,1), 0, 1); Philox4x32-10 keyed by
+ * (seed, offset); noise_out (optional) receives sigma*N(0,1).  qea_jitter_apply takes the
+ * noise as an input instead (parity tests; train_nn_area.py:184-191 returns the noise). */
+int qea_jitter(const float* img, const float* sigma, float* out, float* noise_out, int32_t K, int32_t R, int32_t HW,
+               float coef, uint64_t seed, uint64_t offset, void* stream);
+int qea_jitter_apply(const float* img, const float* noise, float* out, int32_t K, int32_t R, int32_t HW, float coef,
+                     void* stream);
+
+/* TopKCERSampler.query ranking (selection_utils.py:144-151): indices of the k largest keys,
+ * descending, equal keys in ascending index order (stable); n <= 16384. */
+int qea_topk_desc_stable(const float* keys, int32_t n, int32_t k, int64_t* idx_out, void* stream);
+
+/* utils.get_text_stack / padder (utils.py:118-141): crop boxes (x0,y0,x1,y1, already clipped to
+ * the image) out of a [H][W] image, centre on a white OH x OW canvas; scatter is its backward
+ * (adds into dimg). */
+int qea_crop_pad_gather(const float* img, int32_t H, int32_t W, const int32_t* boxes, int32_t N, int32_t OH, int32_t OW,
+                        float* out, void* stream);
+int qea_crop_pad_scatter(const float* dout, const int32_t* boxes, int32_t N, int32_t OH, int32_t OW, float* dimg,
+                         int32_t H, int32_t W, void* stream);
+
+/* utils.pred_to_string (utils.py:74-92): per-step argmax (first maximum), collapse repeats, drop
+ * blank -> tokens [N][T] int32 + lengths [N]; scores element (t,n,c) at t*ld_t + n*ld_n + c. */
+int qea_greedy_decode(const float* scores, int32_t ld_t, int32_t ld_n, int32_t T, int32_t N, int32_t C, int32_t blank,
+                      int32_t* tokens, int32_t* lengths, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

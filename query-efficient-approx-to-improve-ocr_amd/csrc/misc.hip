@@ -1,0 +1,281 @@
+// Small kernels around the networks: fused multi-tensor Adam over flat buffers, per-image
+// Gaussian jitter (Philox4x32-10 + Box-Muller) with replicas fused into the batch dimension,
+// stable descending top-k (TopKCER), crop+pad gather / scatter-add, greedy CTC decode.
+// All HBM- or latency-bound; bytes noted per entry point in include/qea_hip.h.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                            float beta1, float beta2, float eps, float weight_decay, float step_size, float bc2_sqrt, float grad_scale) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gr = gv[k] * grad_scale;
+      if (weight_decay != 0.f) gr += weight_decay * pv[k];
+      mv[k] = mv[k] + (gr - mv[k]) * (1.f - beta1);          // lerp, as torch's exp_avg.lerp_
+      vv[k] = vv[k] * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+      pv[k] = pv[k] - step_size * (mv[k] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  // tail
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gr = g[i] * grad_scale;
+    if (weight_decay != 0.f) gr += weight_decay * p[i];
+    const float mm = m[i] + (gr - m[i]) * (1.f - beta1);
+    const float vv = v[i] * beta2 + (1.f - beta2) * gr * gr;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct U4 { unsigned x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32(U4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
+    U4 n;
+    n.x = (unsigned)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (unsigned)p1;
+    n.z = (unsigned)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (unsigned)p0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+// out[r*K + k][i] = clamp(img[k][i] - coef * sigma[r*K + k] * z, 0, 1), 4 pixels per thread
+__global__ void jitter_kernel(const float* __restrict__ img, const float* __restrict__ sigma, float* __restrict__ out,
+                              float* __restrict__ noise_out, int K, int R, int HW, float coef, unsigned long long seed,
+                              unsigned long long offset) {
+  const long long quads = (long long)R * K * (HW / 4);
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long long)gridDim.x * blockDim.x) {
+    const long long im = q / (HW / 4);
+    const int i4 = (int)(q - im * (HW / 4));
+    const int k = (int)(im % K);
+    U4 ctr;
+    ctr.x = (unsigned)q;
+    ctr.y = (unsigned)(q >> 32);
+    ctr.z = (unsigned)offset;
+    ctr.w = (unsigned)(offset >> 32);
+    const U4 rnd = philox4x32(ctr, (unsigned)seed, (unsigned)(seed >> 32));
+    const float r0 = sqrtf(-2.f * logf(u01(rnd.x))), r1 = sqrtf(-2.f * logf(u01(rnd.z)));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u01(rnd.y), &s0, &c0);
+    sincosf(6.283185307179586f * u01(rnd.w), &s1, &c1);
+    const float sg = sigma[im];
+    f32x4 z = {r0 * c0 * sg, r0 * s0 * sg, r1 * c1 * sg, r1 * s1 * sg};
+    const f32x4 x = *reinterpret_cast<const f32x4*>(img + (size_t)k * HW + i4 * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(x[e] - coef * z[e], 0.f), 1.f);
+    *reinterpret_cast<f32x4*>(out + (size_t)im * HW + i4 * 4) = o;
+    if (noise_out) *reinterpret_cast<f32x4*>(noise_out + (size_t)im * HW + i4 * 4) = z;
+  }
+}
+
+__global__ void jitter_apply_kernel(const float* __restrict__ img, const float* __restrict__ noise, float* __restrict__ out, int K, int R,
+                                    int HW, float coef) {
+  const long long n = (long long)R * K * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long im = i / HW;
+    const int px = (int)(i - im * HW);
+    const int k = (int)(im % K);
+    out[i] = fminf(fmaxf(img[(size_t)k * HW + px] - coef * noise[i], 0.f), 1.f);
+  }
+}
+
+// ------------------------------------------------------------------ top-k (bitonic, one workgroup)
+// total order: larger key first; equal keys -> smaller index first (stable descending)
+__device__ __forceinline__ bool before(float ka, int ia, float kb, int ib) { return (ka > kb) || (ka == kb && ia < ib); }
+
+__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ keys, int n, int npow2, int k, long long* __restrict__ idx_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sk = reinterpret_cast<float*>(smem_raw);
+  int* si = reinterpret_cast<int*>(sk + npow2);
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    sk[i] = (i < n) ? keys[i] : -INFINITY;
+    si[i] = (i < n) ? i : 0x7fffffff;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < npow2 / 2; t += blockDim.x) {
+        const int lo = (t / stride) * (stride << 1) + (t % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);  // ascending position order = "before" order
+        const float ka = sk[lo], kb = sk[hi];
+        const int ia = si[lo], ib = si[hi];
+        const bool swap = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
+        if (swap) {
+          sk[lo] = kb; sk[hi] = ka;
+          si[lo] = ib; si[hi] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) idx_out[i] = (long long)si[i];
+}
+
+// ------------------------------------------------------------------ crop + pad
+struct Box { int x0, y0, x1, y1; };
+
+__global__ void crop_pad_gather_kernel(const float* __restrict__ img, int H, int W, const int* __restrict__ boxes, int N, int OH, int OW,
+                                       float* __restrict__ out) {
+  const long long n_el = (long long)N * OH * OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int oy = (int)((i / OW) % OH);
+    const int n = (int)(i / ((long long)OW * OH));
+    const int x0 = boxes[n * 4 + 0], y0 = boxes[n * 4 + 1], x1 = boxes[n * 4 + 2], y1 = boxes[n * 4 + 3];
+    const int cw = x1 - x0, ch = y1 - y0;
+    const int left = (OW - cw) / 2, top = (OH - ch) / 2;
+    const int sx = ox - left, sy = oy - top;
+    float v = 1.f;
+    if (sx >= 0 && sx < cw && sy >= 0 && sy < ch) v = img[(size_t)(y0 + sy) * W + x0 + sx];
+    out[i] = v;
+  }
+}
+
+__global__ void crop_pad_scatter_kernel(const float* __restrict__ dout, const int* __restrict__ boxes, int N, int OH, int OW, float* dimg,
+                                        int H, int W) {
+  const long long n_el = (long long)N * OH * OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int oy = (int)((i / OW) % OH);
+    const int n = (int)(i / ((long long)OW * OH));
+    const int x0 = boxes[n * 4 + 0], y0 = boxes[n * 4 + 1], x1 = boxes[n * 4 + 2], y1 = boxes[n * 4 + 3];
+    const int cw = x1 - x0, ch = y1 - y0;
+    const int left = (OW - cw) / 2, top = (OH - ch) / 2;
+    const int sx = ox - left, sy = oy - top;
+    if (sx >= 0 && sx < cw && sy >= 0 && sy < ch) atomicAdd(dimg + (size_t)(y0 + sy) * W + x0 + sx, dout[i]);
+  }
+}
+
+// ------------------------------------------------------------------ greedy CTC decode
+// one wave per sample: argmax over C per step (first maximum), collapse repeats, drop blank
+__global__ __launch_bounds__(64) void greedy_decode_kernel(const float* __restrict__ scores, int ld_t, int ld_n, int T, int N, int C, int blank,
+                                                           int* __restrict__ tokens, int* __restrict__ lengths) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  int prev = -1, len = 0;
+  for (int t = 0; t < T; ++t) {
+    const float* row = scores + (size_t)t * ld_t + (size_t)n * ld_n;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float v = row[c];
+      if (v > best || (v == best && c < bi) || (v != v && best == best)) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    // reference quirk (utils.py:85-88): the first emitted char does not look at the previous index
+    if (bi != blank && (len == 0 || bi != prev)) {
+      if (lane == 0) tokens[(size_t)n * T + len] = bi;
+      ++len;
+    }
+    prev = bi;
+  }
+  if (lane == 0) lengths[n] = len;
+}
+
+int grid_for(long long n, int cap = 4096) {
+  long long g = (n + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int qea_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int64_t step, float grad_scale, void* stream) {
+  QEA_REQUIRE(p && g && m && v && n > 0 && step >= 1, "qea_adam_step: bad arguments");
+  QEA_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "qea_adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
+                     weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_jitter(const float* img, const float* sigma, float* out, float* noise_out, int32_t K, int32_t R, int32_t HW, float coef,
+                          uint64_t seed, uint64_t offset, void* stream) {
+  QEA_REQUIRE(img && sigma && out && K > 0 && R > 0 && HW > 0 && HW % 4 == 0, "qea_jitter: bad arguments (HW must be a multiple of 4)");
+  hipLaunchKernelGGL(jitter_kernel, dim3(grid_for((long long)R * K * (HW / 4))), dim3(256), 0, (hipStream_t)stream, img, sigma, out, noise_out,
+                     K, R, HW, coef, (unsigned long long)seed, (unsigned long long)offset);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_jitter_apply(const float* img, const float* noise, float* out, int32_t K, int32_t R, int32_t HW, float coef, void* stream) {
+  QEA_REQUIRE(img && noise && out && K > 0 && R > 0 && HW > 0, "qea_jitter_apply: bad arguments");
+  hipLaunchKernelGGL(jitter_apply_kernel, dim3(grid_for((long long)R * K * HW)), dim3(256), 0, (hipStream_t)stream, img, noise, out, K, R, HW,
+                     coef);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_topk_desc_stable(const float* keys, int32_t n, int32_t k, int64_t* idx_out, void* stream) {
+  QEA_REQUIRE(keys && idx_out && n > 0 && k > 0 && k <= n, "qea_topk_desc_stable: bad arguments");
+  QEA_REQUIRE(n <= 16384, "qea_topk_desc_stable: n=%d > 16384 not supported", n);
+  int npow2 = 2;
+  while (npow2 < n) npow2 <<= 1;
+  const size_t lds = (size_t)npow2 * 8;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+    attr = true;
+  }
+  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, keys, n, npow2, k, (long long*)idx_out);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_crop_pad_gather(const float* img, int32_t H, int32_t W, const int32_t* boxes, int32_t N, int32_t OH, int32_t OW, float* out,
+                                   void* stream) {
+  QEA_REQUIRE(img && boxes && out && H > 0 && W > 0 && N > 0 && OH > 0 && OW > 0, "qea_crop_pad_gather: bad arguments");
+  hipLaunchKernelGGL(crop_pad_gather_kernel, dim3(grid_for((long long)N * OH * OW)), dim3(256), 0, (hipStream_t)stream, img, H, W, boxes, N,
+                     OH, OW, out);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_crop_pad_scatter(const float* dout, const int32_t* boxes, int32_t N, int32_t OH, int32_t OW, float* dimg, int32_t H,
+                                    int32_t W, void* stream) {
+  QEA_REQUIRE(dout && boxes && dimg && H > 0 && W > 0 && N > 0 && OH > 0 && OW > 0, "qea_crop_pad_scatter: bad arguments");
+  hipLaunchKernelGGL(crop_pad_scatter_kernel, dim3(grid_for((long long)N * OH * OW)), dim3(256), 0, (hipStream_t)stream, dout, boxes, N, OH, OW,
+                     dimg, H, W);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_greedy_decode(const float* scores, int32_t ld_t, int32_t ld_n, int32_t T, int32_t N, int32_t C, int32_t blank,
+                                 int32_t* tokens, int32_t* lengths, void* stream) {
+  QEA_REQUIRE(scores && tokens && lengths && T > 0 && N > 0 && C > 0, "qea_greedy_decode: bad arguments");
+  hipLaunchKernelGGL(greedy_decode_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, scores, ld_t, ld_n, T, N, C, blank, tokens, lengths);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}

@@ -1,0 +1,448 @@
+// HBM-bound NHWC kernels between the convolutions: BatchNorm (batch statistics in fp64,
+// apply + ReLU, backward), max-pool forward/backward (+ fused ReLU mask), per-channel column
+// sums (bias gradients), 2-D transposes / filter flips for the gradient GEMMs.
+// All of them stream float4 per lane over [pixels][channels] rows; roofline = HBM (~6.3 TB/s
+// achievable), algorithmic bytes = 4 * (tensors read + tensors written) * M * C.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+
+// ------------------------------------------------------------------ column reductions
+// Each block owns a contiguous range of rows; thread (rt, ct) accumulates 4 channels
+// (one float4 column) over rows rt, rt+RT, ... in fp64; LDS tree over rt; partial -> ws.
+struct ColGeom {
+  int cols;  // C/4 float4 columns
+  int rt;    // row-threads per block
+  int grid;
+  int rows_per_block;
+};
+
+ColGeom col_geom(long long M, int C) {
+  ColGeom g;
+  g.cols = C / 4;
+  g.rt = RED_THREADS / g.cols;
+  if (g.rt < 1) g.rt = 1;
+  long long want = (M + (long long)g.rt * 16 - 1) / ((long long)g.rt * 16);
+  if (want > 1024) want = 1024;
+  if (want < 1) want = 1;
+  g.grid = (int)want;
+  g.rows_per_block = (int)((M + g.grid - 1) / g.grid);
+  g.grid = (int)((M + g.rows_per_block - 1) / g.rows_per_block);
+  return g;
+}
+
+// MODE 0: s0 = sum x, s1 = sum x^2                                 (BN statistics)
+// MODE 1: dz = da * (a > 0 if a else 1); s0 = sum dz, s1 = sum dz * (y - mean) * invstd   (BN backward)
+// MODE 2: s0 = sum x                                               (bias gradient)
+template <int MODE>
+__global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ a,
+                                                                  int lda, const float* __restrict__ y, int ldy,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  long long M, int C, int rows_per_block, int rt_n, double* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) double sred[];  // [rt_n][cols*4][2]
+  const int cols = C / 4;
+  const int ct = threadIdx.x % cols, rt = threadIdx.x / cols;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (rt < rt_n) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const f32x4*>(mean + ct * 4);
+      is = *reinterpret_cast<const f32x4*>(invstd + ct * 4);
+    }
+    for (long long r = r0 + rt; r < r1; r += rt_n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + ct * 4);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s0[k] += (double)v[k];
+          s1[k] += (double)v[k] * (double)v[k];
+        }
+      } else if (MODE == 1) {
+        f32x4 dz = v;
+        if (a) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(a + r * lda + ct * 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
+        }
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s0[k] += (double)dz[k];
+          s1[k] += (double)dz[k] * (double)((yv[k] - mu[k]) * is[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s0[k] += (double)v[k];
+      }
+    }
+  }
+  if (rt < rt_n) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sred[((size_t)rt * C + ct * 4 + k) * 2 + 0] = s0[k];
+      sred[((size_t)rt * C + ct * 4 + k) * 2 + 1] = s1[k];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double t0 = 0, t1 = 0;
+    for (int r = 0; r < rt_n; ++r) {
+      t0 += sred[((size_t)r * C + c) * 2 + 0];
+      t1 += sred[((size_t)r * C + c) * 2 + 1];
+    }
+    ws[((size_t)blockIdx.x * C + c) * 2 + 0] = t0;
+    ws[((size_t)blockIdx.x * C + c) * 2 + 1] = t1;
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ ws, int nblk, int C, long long M, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                         float* running_var, float* mean_out, float* invstd_out, float* scale_out, float* shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int b = 0; b < nblk; ++b) {
+    s += ws[((size_t)b * C + c) * 2 + 0];
+    q += ws[((size_t)b * C + c) * 2 + 1];
+  }
+  const double mean = s / (double)M;
+  double var = q / (double)M - mean * mean;  // biased (normalisation)
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  scale_out[c] = g * invstd;
+  shift_out[c] = b - (float)mean * g * invstd;
+  if (running_mean) {
+    const double unb = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                     const float* __restrict__ conv_bias, float* mean_out, float* invstd_out, float* scale_out,
+                                     float* shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rvar[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_out[c] = rmean[c];
+  invstd_out[c] = invstd;
+  scale_out[c] = g * invstd;
+  shift_out[c] = b + ((conv_bias ? conv_bias[c] : 0.f) - rmean[c]) * g * invstd;
+}
+
+__global__ void colsum_finalize_kernel(const double* __restrict__ ws, int nblk, int C, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0;
+  for (int b = 0; b < nblk; ++b) s += ws[((size_t)b * C + c) * 2 + 0];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, int C, long long M, const float* __restrict__ gamma,
+                                       const float* __restrict__ invstd, int training, float* dgamma, float* dbeta, int accumulate,
+                                       float* k0, float* k1, float* k2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int b = 0; b < nblk; ++b) {
+    s += ws[((size_t)b * C + c) * 2 + 0];
+    q += ws[((size_t)b * C + c) * 2 + 1];
+  }
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+  const float g = gamma ? gamma[c] : 1.f;
+  k0[c] = g * invstd[c];                           // dy = k0 * (dz - k1 - xhat * k2)
+  k1[c] = training ? (float)(s / (double)M) : 0.f;
+  k2[c] = training ? (float)(q / (double)M) : 0.f;
+}
+
+// ------------------------------------------------------------------ elementwise
+__global__ void bn_apply_kernel(const float* __restrict__ y, int ldy, float* __restrict__ a, int lda, long long M, int C,
+                                const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+  const int cols = C / 4;
+  const long long n = M * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols;
+    const int ct = (int)(i - r * cols);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ct * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ct * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = v[k] * sc[k] + sh[k];
+      if (relu) o[k] = fmaxf(o[k], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(a + r * lda + ct * 4) = o;
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ a, int lda,
+                                    const float* __restrict__ y, int ldy, float* __restrict__ dy, int lddy, long long M, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k0,
+                                    const float* __restrict__ k1, const float* __restrict__ k2) {
+  const int cols = C / 4;
+  const long long n = M * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols;
+    const int ct = (int)(i - r * cols);
+    f32x4 dz = *reinterpret_cast<const f32x4*>(da + r * ldda + ct * 4);
+    if (a) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(a + r * lda + ct * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
+    }
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ct * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + ct * 4);
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(k0 + ct * 4);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(k1 + ct * 4);
+    const f32x4 c2 = *reinterpret_cast<const f32x4*>(k2 + ct * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = c0[k] * (dz[k] - c1[k] - (yv[k] - mu[k]) * is[k] * c2[k]);
+    *reinterpret_cast<f32x4*>(dy + r * lddy + ct * 4) = o;
+  }
+}
+
+// max-pool with window == stride (2x2 or 2x1), PyTorch tie rule: first maximum in (kh,kw) scan order
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C,
+                                   int kh, int kw) {
+  const int OH = H / kh, OW = W / kw, cols = C / 4;
+  const long long n = (long long)B * OH * OW * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ct = (int)(i % cols);
+    const long long op = i / cols;
+    const int ow = (int)(op % OW);
+    const int oh = (int)((op / OW) % OH);
+    const int b = (int)(op / ((long long)OW * OH));
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int i2 = 0; i2 < kh; ++i2)
+      for (int j2 = 0; j2 < kw; ++j2) {
+        const long long ip = ((long long)b * H + oh * kh + i2) * W + ow * kw + j2;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ip * ldx + ct * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = (v[k] > m[k] || v[k] != v[k]) ? v[k] : m[k];
+      }
+    *reinterpret_cast<f32x4*>(y + op * ldy + ct * 4) = m;
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, float* __restrict__ dx,
+                                   int lddx, int B, int H, int W, int C, int kh, int kw, int relu_mask, int accumulate) {
+  const int OH = H / kh, OW = W / kw, cols = C / 4;
+  const long long n = (long long)B * OH * OW * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ct = (int)(i % cols);
+    const long long op = i / cols;
+    const int ow = (int)(op % OW);
+    const int oh = (int)((op / OW) % OH);
+    const int b = (int)(op / ((long long)OW * OH));
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {0, 0, 0, 0};
+    for (int i2 = 0; i2 < kh; ++i2)
+      for (int j2 = 0; j2 < kw; ++j2) {
+        const long long ip = ((long long)b * H + oh * kh + i2) * W + ow * kw + j2;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ip * ldx + ct * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (v[k] > m[k] || v[k] != v[k]) {
+            m[k] = v[k];
+            arg[k] = i2 * kw + j2;
+          }
+      }
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + op * lddy + ct * 4);
+    for (int i2 = 0; i2 < kh; ++i2)
+      for (int j2 = 0; j2 < kw; ++j2) {
+        const long long ip = ((long long)b * H + oh * kh + i2) * W + ow * kw + j2;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = (arg[k] == i2 * kw + j2) ? g[k] : 0.f;
+          if (relu_mask && !(m[k] > 0.f)) t = 0.f;
+          o[k] = t;
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(dx + ip * lddx + ct * 4);
+        if (accumulate) o += *dst;
+        *dst = o;
+      }
+  }
+}
+
+// out[c][r] = in[r][c]  (32x32 LDS tiles)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+  __shared__ float t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    t[j][tx] = (r < R && c < Cc) ? in[(size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (c < Cc && r < R) out[(size_t)c * R + r] = t[tx][j];
+  }
+}
+
+// conv weight [Co][KH][KW][Ci] -> input-gradient filter [Ci][KH][KW][Co] with taps flipped
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int Ci, int KH, int KW) {
+  const long long n = (long long)Co * KH * KW * Ci;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    // i indexes wt: (ci, kh', kw', co), co fastest
+    const int co = (int)(i % Co);
+    long long r = i / Co;
+    const int kw2 = (int)(r % KW);
+    r /= KW;
+    const int kh2 = (int)(r % KH);
+    const int ci = (int)(r / KH);
+    wt[i] = w[(((size_t)co * KH + (KH - 1 - kh2)) * KW + (KW - 1 - kw2)) * Ci + ci];
+  }
+}
+
+int grid_for(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int check_nc(const char* who, long long M, int C, size_t ws_bytes, void* ws, const ColGeom& g) {
+  QEA_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C / 4 <= RED_THREADS, "%s: need C %% 4 == 0 and C <= %d (C=%d)", who, 4 * RED_THREADS, C);
+  QEA_REQUIRE(ws && ws_bytes >= (size_t)g.grid * C * 2 * sizeof(double), "%s: workspace too small", who);
+  return QEA_OK;
+}
+
+}  // namespace
+
+extern "C" size_t qea_colreduce_workspace_bytes(int64_t M, int32_t C) {
+  if (M <= 0 || C <= 0 || C % 4) return 0;
+  const ColGeom g = col_geom(M, C);
+  return (size_t)g.grid * C * 2 * sizeof(double) + 3 * (size_t)C * sizeof(float);
+}
+
+extern "C" int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, float* mean_out, float* invstd_out,
+                                  float* scale_out, float* shift_out, void* workspace, size_t workspace_bytes, void* stream) {
+  QEA_REQUIRE(y && mean_out && invstd_out && scale_out && shift_out, "qea_bn_train_stats: null pointer");
+  const ColGeom g = col_geom(M, C);
+  int rc = check_nc("qea_bn_train_stats", M, C, workspace_bytes, workspace, g);
+  if (rc) return rc;
+  QEA_REQUIRE(ldy % 4 == 0 && ((uintptr_t)y & 15) == 0, "qea_bn_train_stats: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
+  hipLaunchKernelGGL(colreduce_kernel<0>, dim3(g.grid), dim3(RED_THREADS), lds, s, y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                     (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, g.grid, C,
+                     (long long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                 float eps, const float* conv_bias, float* mean_out, float* invstd_out, float* scale_out,
+                                 float* shift_out, void* stream) {
+  QEA_REQUIRE(C > 0 && running_mean && running_var && mean_out && invstd_out && scale_out && shift_out, "qea_bn_eval_coeff: null pointer");
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, C, gamma, beta, running_mean,
+                     running_var, eps, conv_bias, mean_out, invstd_out, scale_out, shift_out);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, int64_t M, int32_t C, const float* scale,
+                            const float* shift, int32_t relu, void* stream) {
+  QEA_REQUIRE(y && a && scale && shift && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && lda % 4 == 0, "qea_bn_apply: bad arguments");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, a, lda, (long long)M, C,
+                     scale, shift, relu);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* y, int32_t ldy, int64_t M, int32_t C,
+                          const float* gamma, const float* mean, const float* invstd, int32_t training, float* dgamma, float* dbeta,
+                          int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  QEA_REQUIRE(da && y && mean && invstd && dy, "qea_bn_bwd: null pointer");
+  const ColGeom g = col_geom(M, C);
+  int rc = check_nc("qea_bn_bwd", M, C, workspace_bytes, workspace, g);
+  if (rc) return rc;
+  QEA_REQUIRE(workspace_bytes >= qea_colreduce_workspace_bytes(M, C), "qea_bn_bwd: workspace too small");
+  QEA_REQUIRE(ldda % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!a || lda % 4 == 0), "qea_bn_bwd: strides must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  double* ws = (double*)workspace;
+  float* k0 = (float*)(ws + (size_t)g.grid * C * 2);
+  float* k1 = k0 + C;
+  float* k2 = k1 + C;
+  const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
+  hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.grid), dim3(RED_THREADS), lds, s, da, ldda, a, lda, y, ldy, mean, invstd, (long long)M, C,
+                     g.rows_per_block, g.rt, ws);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)ws, g.grid, C, (long long)M, gamma,
+                     invstd, training, dgamma, dbeta, accumulate_param_grads, k0, k1, k2);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, s, da, ldda, a, lda, y, ldy, dy, lddy, (long long)M, C,
+                     mean, invstd, (const float*)k0, (const float*)k1, (const float*)k2);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, float* out, int32_t accumulate, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  QEA_REQUIRE(x && out, "qea_colsum: null pointer");
+  const ColGeom g = col_geom(M, C);
+  int rc = check_nc("qea_colsum", M, C, workspace_bytes, workspace, g);
+  if (rc) return rc;
+  QEA_REQUIRE(ldx % 4 == 0, "qea_colsum: ldx must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
+  hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.grid), dim3(RED_THREADS), lds, s, x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                     (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, g.grid, C, out, accumulate);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_maxpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t kh,
+                               int32_t kw, void* stream) {
+  QEA_REQUIRE(x && y && B > 0 && C > 0 && C % 4 == 0 && kh > 0 && kw > 0 && H % kh == 0 && W % kw == 0 && ldx % 4 == 0 && ldy % 4 == 0,
+              "qea_maxpool_fwd: bad arguments (H,W must be multiples of the window; C, ld multiples of 4)");
+  const long long n = (long long)B * (H / kh) * (W / kw) * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, kh, kw);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_maxpool_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H,
+                               int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t relu_mask, int32_t accumulate, void* stream) {
+  QEA_REQUIRE(x && dy && dx && B > 0 && C > 0 && C % 4 == 0 && kh > 0 && kw > 0 && H % kh == 0 && W % kw == 0 && ldx % 4 == 0 &&
+                  lddy % 4 == 0 && lddx % 4 == 0,
+              "qea_maxpool_bwd: bad arguments");
+  const long long n = (long long)B * (H / kh) * (W / kw) * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, dx, lddx, B, H, W, C, kh,
+                     kw, relu_mask, accumulate);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_transpose2d(const float* in, float* out, int32_t R, int32_t Cc, void* stream) {
+  QEA_REQUIRE(in && out && R > 0 && Cc > 0, "qea_transpose2d: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3(qea_cdiv(Cc, 32), qea_cdiv(R, 32)), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_filter_flip_transpose(const float* w, float* wt, int32_t Co, int32_t Ci, int32_t KH, int32_t KW, void* stream) {
+  QEA_REQUIRE(w && wt && Co > 0 && Ci > 0 && KH > 0 && KW > 0, "qea_filter_flip_transpose: bad arguments");
+  hipLaunchKernelGGL(flip_transpose_kernel, dim3(grid_for((long long)Co * Ci * KH * KW)), dim3(256), 0, (hipStream_t)stream, w, wt, Co, Ci,
+                     KH, KW);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}

@@ -1,39 +1,23 @@
 """ctypes binding of libqea_hip.so (the C ABI declared in include/qea_hip.h).
 
+Prototypes are read from the header itself, so the Python side cannot drift from the ABI.
 There is deliberately no fallback: if the shared library is missing or a call fails the
 caller gets an exception, never a silently different code path.
 """
 import ctypes as C
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libqea_hip.so")
+PKG_DIR = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_DIR, "libqea_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "qea_hip.h")
 
 _lib = None
 
 
 class QeaError(RuntimeError):
     pass
-
-
-def lib():
-    """Load (once) and return the CDLL; raises QeaError if it is not built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise QeaError(
-                f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
-                "(hipcc --offload-arch=gfx950); there is no CPU fallback"
-            )
-        _lib = C.CDLL(LIB_PATH)
-        _declare(_lib)
-    return _lib
-
-
-def check(rc, what=""):
-    if rc != 0:
-        msg = lib().qea_last_error().decode("utf-8", "replace")
-        raise QeaError(f"{what} failed ({rc}): {msg}")
 
 
 _fp = C.c_void_p
@@ -61,13 +45,53 @@ class WgradDesc(C.Structure):
     ]
 
 
-def _declare(L):
-    L.qea_version.restype = C.c_int
-    L.qea_last_error.restype = C.c_char_p
-    L.qea_prof_enable.argtypes = [C.c_int, C.c_int]
-    L.qea_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    L.qea_conv_igemm.argtypes = [C.POINTER(ConvDesc), _fp]
-    L.qea_conv_wgrad.argtypes = [C.POINTER(WgradDesc), _fp]
-    L.qea_conv_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
-    L.qea_conv_wgrad_workspace_bytes.restype = C.c_size_t
+_SCALARS = {
+    "int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
+    "size_t": C.c_size_t, "float": C.c_float, "double": C.c_double,
+}
+_PROTO = re.compile(r"^(int|size_t|const char\*)\s+(qea_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
+
+
+def header_prototypes(path=HEADER_PATH):
+    """[(name, restype, [argtypes])] for every function the header declares."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = []
+    for ret, name, args in _PROTO.findall(text):
+        restype = {"int": C.c_int, "size_t": C.c_size_t, "const char*": C.c_char_p}[ret]
+        argtypes = []
+        args = " ".join(args.split())
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(C.c_void_p)
+                else:
+                    ty = a.replace("const ", "").split()[0]
+                    argtypes.append(_SCALARS[ty])
+        out.append((name, restype, argtypes))
+    return out
+
+
+def lib():
+    """Load (once) and return the CDLL; raises QeaError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QeaError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback"
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, restype, argtypes in header_prototypes():
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().qea_last_error().decode("utf-8", "replace")
+        raise QeaError(f"{what} failed ({rc}): {msg}")

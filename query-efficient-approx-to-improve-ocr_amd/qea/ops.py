@@ -76,3 +76,150 @@ def prof_read(klass):
     ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
     _lib.check(_lib.lib().qea_prof_read(klass, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "qea_prof_read")
     return {"ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value}
+
+
+# ----------------------------------------------------------------------------- BN / pool / misc
+def _colws(M, C_, device):
+    need = _lib.lib().qea_colreduce_workspace_bytes(M, C_)
+    ws = workspace(need, device)
+    return ws.data_ptr(), ws.numel()
+
+
+def bn_train_stats(y, ldy, M, C_, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift):
+    wp, wn = _colws(M, C_, y.device)
+    _lib.check(_lib.lib().qea_bn_train_stats(_ptr(y), ldy, M, C_, _ptr(gamma), _ptr(beta), eps, momentum,
+                                             _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
+                                             _ptr(scale), _ptr(shift), wp, wn, _stream()), "qea_bn_train_stats")
+
+
+def bn_eval_coeff(C_, gamma, beta, running_mean, running_var, eps, conv_bias, mean, invstd, scale, shift):
+    _lib.check(_lib.lib().qea_bn_eval_coeff(C_, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps,
+                                            _ptr(conv_bias), _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift),
+                                            _stream()), "qea_bn_eval_coeff")
+
+
+def bn_apply(y, ldy, a, lda, M, C_, scale, shift, relu=True):
+    _lib.check(_lib.lib().qea_bn_apply(_ptr(y), ldy, _ptr(a), lda, M, C_, _ptr(scale), _ptr(shift), int(relu), _stream()),
+               "qea_bn_apply")
+
+
+def bn_bwd(da, ldda, a, lda, y, ldy, M, C_, gamma, mean, invstd, training, dgamma, dbeta, dy, lddy, accumulate=False):
+    wp, wn = _colws(M, C_, da.device)
+    _lib.check(_lib.lib().qea_bn_bwd(_ptr(da), ldda, _ptr(a), lda, _ptr(y), ldy, M, C_, _ptr(gamma), _ptr(mean),
+                                     _ptr(invstd), int(training), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(dy),
+                                     lddy, wp, wn, _stream()), "qea_bn_bwd")
+
+
+def colsum(x, ldx, M, C_, out, accumulate=False):
+    wp, wn = _colws(M, C_, x.device)
+    _lib.check(_lib.lib().qea_colsum(_ptr(x), ldx, M, C_, _ptr(out), int(accumulate), wp, wn, _stream()), "qea_colsum")
+
+
+def maxpool_fwd(x, ldx, y, ldy, B, H, W, C_, kh, kw):
+    _lib.check(_lib.lib().qea_maxpool_fwd(_ptr(x), ldx, _ptr(y), ldy, B, H, W, C_, kh, kw, _stream()), "qea_maxpool_fwd")
+
+
+def maxpool_bwd(x, ldx, dy, lddy, dx, lddx, B, H, W, C_, kh, kw, relu_mask=False, accumulate=False):
+    _lib.check(_lib.lib().qea_maxpool_bwd(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, B, H, W, C_, kh, kw,
+                                          int(relu_mask), int(accumulate), _stream()), "qea_maxpool_bwd")
+
+
+def transpose2d(src, dst, R, Cc):
+    _lib.check(_lib.lib().qea_transpose2d(_ptr(src), _ptr(dst), R, Cc, _stream()), "qea_transpose2d")
+
+
+def filter_flip_transpose(w, wt, Co, Ci, KH, KW):
+    _lib.check(_lib.lib().qea_filter_flip_transpose(_ptr(w), _ptr(wt), Co, Ci, KH, KW, _stream()), "qea_filter_flip_transpose")
+
+
+# ----------------------------------------------------------------------------- single-channel convs / head
+def conv_c1_fwd(x, w, bias, y, ldy, B, H, W, Co, relu=False):
+    _lib.check(_lib.lib().qea_conv_c1_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), ldy, B, H, W, Co, int(relu), _stream()),
+               "qea_conv_c1_fwd")
+
+
+def conv_c1_wgrad(x, dy, lddy, dw, db, B, H, W, Co, accumulate=False):
+    L = _lib.lib()
+    ws = workspace(L.qea_conv_c1_wgrad_workspace_bytes(B, H, W, Co), x.device)
+    _lib.check(L.qea_conv_c1_wgrad(_ptr(x), _ptr(dy), lddy, _ptr(dw), _ptr(db), B, H, W, Co, int(accumulate),
+                                   ws.data_ptr(), ws.numel(), _stream()), "qea_conv_c1_wgrad")
+
+
+def conv_c1_dgrad(dy, lddy, w, dx, B, H, W, Co, accumulate=False):
+    _lib.check(_lib.lib().qea_conv_c1_dgrad(_ptr(dy), lddy, _ptr(w), _ptr(dx), B, H, W, Co, int(accumulate), _stream()),
+               "qea_conv_c1_dgrad")
+
+
+def head_fwd(x, ldx, w, b, y, M, C_):
+    _lib.check(_lib.lib().qea_head_fwd(_ptr(x), ldx, _ptr(w), _ptr(b), _ptr(y), M, C_, _stream()), "qea_head_fwd")
+
+
+def head_bwd(x, ldx, y, dyy, w, dx, lddx, dw, db, M, C_, accumulate=False):
+    L = _lib.lib()
+    ws = workspace(L.qea_head_bwd_workspace_bytes(M, C_), x.device)
+    _lib.check(L.qea_head_bwd(_ptr(x), ldx, _ptr(y), _ptr(dyy), _ptr(w), _ptr(dx), lddx, _ptr(dw), _ptr(db),
+                              int(accumulate), M, C_, ws.data_ptr(), ws.numel(), _stream()), "qea_head_bwd")
+
+
+# ----------------------------------------------------------------------------- sequence ops
+def lstm_pack_whh(w_hh, packed_fwd, packed_bwd):
+    _lib.check(_lib.lib().qea_lstm_pack_whh(_ptr(w_hh), _ptr(packed_fwd), _ptr(packed_bwd), _stream()), "qea_lstm_pack_whh")
+
+
+def lstm_layer_fwd(gates, c, y, packed_fwd, T, B):
+    _lib.check(_lib.lib().qea_lstm_layer_fwd(_ptr(gates), _ptr(c), _ptr(y), _ptr(packed_fwd), T, B, _stream()), "qea_lstm_layer_fwd")
+
+
+def lstm_layer_bwd(gates, c, dy, packed_bwd, dc_scratch, T, B):
+    _lib.check(_lib.lib().qea_lstm_layer_bwd(_ptr(gates), _ptr(c), _ptr(dy), _ptr(packed_bwd), _ptr(dc_scratch), T, B,
+                                             _stream()), "qea_lstm_layer_bwd")
+
+
+def log_softmax_fwd(x, ldx, y, ldy, M, C_):
+    _lib.check(_lib.lib().qea_log_softmax_fwd(_ptr(x), ldx, _ptr(y), ldy, M, C_, _stream()), "qea_log_softmax_fwd")
+
+
+def log_softmax_bwd(g, ldg, lp, ldlp, dx, lddx, M, C_, Cpad, nan_scrub):
+    _lib.check(_lib.lib().qea_log_softmax_bwd(_ptr(g), ldg, _ptr(lp), ldlp, _ptr(dx), lddx, M, C_, Cpad, int(nan_scrub),
+                                              _stream()), "qea_log_softmax_bwd")
+
+
+def ctc_loss(lp, ld_t, ld_n, targets, target_offsets, input_lengths, target_lengths, T, N, C_, blank, S_max, reduction,
+             grad_scale, nll, loss, grad, gld_t, gld_n):
+    L = _lib.lib()
+    ws = workspace(L.qea_ctc_workspace_bytes(T, N, S_max), lp.device)
+    _lib.check(L.qea_ctc_loss(_ptr(lp), ld_t, ld_n, _ptr(targets), _ptr(target_offsets), _ptr(input_lengths),
+                              _ptr(target_lengths), T, N, C_, blank, S_max, reduction, grad_scale, _ptr(nll), _ptr(loss),
+                              _ptr(grad), gld_t, gld_n, ws.data_ptr(), ws.numel(), _stream()), "qea_ctc_loss")
+
+
+# ----------------------------------------------------------------------------- optimiser / jitter / selection / crops
+def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _lib.check(_lib.lib().qea_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, weight_decay, step,
+                                        grad_scale, _stream()), "qea_adam_step")
+
+
+def jitter(img, sigma, out, noise_out, K, R, HW, coef, seed, offset):
+    _lib.check(_lib.lib().qea_jitter(_ptr(img), _ptr(sigma), _ptr(out), _ptr(noise_out), K, R, HW, coef, seed, offset,
+                                     _stream()), "qea_jitter")
+
+
+def jitter_apply(img, noise, out, K, R, HW, coef):
+    _lib.check(_lib.lib().qea_jitter_apply(_ptr(img), _ptr(noise), _ptr(out), K, R, HW, coef, _stream()), "qea_jitter_apply")
+
+
+def topk_desc_stable(keys, n, k, idx_out):
+    _lib.check(_lib.lib().qea_topk_desc_stable(_ptr(keys), n, k, _ptr(idx_out), _stream()), "qea_topk_desc_stable")
+
+
+def crop_pad_gather(img, H, W, boxes, N, OH, OW, out):
+    _lib.check(_lib.lib().qea_crop_pad_gather(_ptr(img), H, W, _ptr(boxes), N, OH, OW, _ptr(out), _stream()), "qea_crop_pad_gather")
+
+
+def crop_pad_scatter(dout, boxes, N, OH, OW, dimg, H, W):
+    _lib.check(_lib.lib().qea_crop_pad_scatter(_ptr(dout), _ptr(boxes), N, OH, OW, _ptr(dimg), H, W, _stream()), "qea_crop_pad_scatter")
+
+
+def greedy_decode(scores, ld_t, ld_n, T, N, C_, blank, tokens, lengths):
+    _lib.check(_lib.lib().qea_greedy_decode(_ptr(scores), ld_t, ld_n, T, N, C_, blank, _ptr(tokens), _ptr(lengths), _stream()),
+               "qea_greedy_decode")
