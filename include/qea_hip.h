@@ -123,12 +123,15 @@ int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream);
  * qea_bn_bwd         : dz = da * (a > 0) [a may be NULL: no ReLU]; dgamma = sum dz*xhat,
  *                      dbeta = sum dz; training: dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)),
  *                      eval: dy = scale*dz.  dy may alias da.
+ * stat64 (optional, [2][C] doubles): the batch mean and invstd unrounded; handing it back to
+ * qea_bn_bwd keeps the per-channel constants of the backward in fp64 — they are common to every
+ * pixel, so fp32 rounding of them is a CORRELATED error that later per-channel sums amplify by M.
  * Workspace for stats / bwd / colsum: qea_colreduce_workspace_bytes(M, C).
  * ---------------------------------------------------------------------------------- */
 size_t qea_colreduce_workspace_bytes(int64_t M, int32_t C);
 int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* beta,
                        float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
-                       float* invstd_out, float* scale_out, float* shift_out, void* workspace,
+                       float* invstd_out, float* scale_out, float* shift_out, double* stat64, void* workspace,
                        size_t workspace_bytes, void* stream);
 int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, const float* conv_bias, float* mean_out,
@@ -136,9 +139,9 @@ int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* beta, const fl
 int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, int64_t M, int32_t C, const float* scale,
                  const float* shift, int32_t relu, void* stream);
 int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* y, int32_t ldy, int64_t M,
-               int32_t C, const float* gamma, const float* mean, const float* invstd, int32_t training,
-               float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy, int32_t lddy,
-               void* workspace, size_t workspace_bytes, void* stream);
+               int32_t C, const float* gamma, const float* mean, const float* invstd, const double* stat64,
+               int32_t training, float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy,
+               int32_t lddy, void* workspace, size_t workspace_bytes, void* stream);
 /* out[c] (+)= sum_m x[m][c]  — conv / linear / LSTM bias gradients */
 int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, float* out, int32_t accumulate, void* workspace,
                size_t workspace_bytes, void* stream);

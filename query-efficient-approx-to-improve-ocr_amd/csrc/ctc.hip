@@ -1,6 +1,11 @@
 // log_softmax (+ backward with the reference's NaN scrub) and the CTC loss / gradient.
 //
-// CTC follows ATen's native recursion (Graves 2006 eq. 6-16 in log space, fp32):
+// CTC follows ATen's native recursion (Graves 2006 eq. 6-16 in log space).  The recursion, the
+// per-sample nll and the gradient formula run in fp64 (inputs/outputs fp32): with |log-likelihood|
+// ~ 1e2 an fp32 recursion carries ~1e-5 absolute error into exp(alpha+beta+nll-lp), i.e. a 1e-5..1e-4
+// RELATIVE error common to every (t,c) of a sample, which per-channel sums downstream amplify
+// (measured: bias gradients 4-7x further from the exact value than ATen's fp32 path).  fp64 costs
+// nothing here (latency-bound scan, 2*T*S values per sample).
 //   alpha_t(s) = lse(alpha_{t-1}(s), alpha_{t-1}(s-1), [alpha_{t-1}(s-2)]) + lp[t, l'_s]
 // one workgroup per sample, one thread per extended-label state (S = 2L+1 <= 256),
 // one barrier per time step; alpha and beta go to a caller-owned workspace and a second kernel
@@ -13,15 +18,16 @@ namespace {
 
 constexpr int CTC_MAX_S = 256;
 
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-  const float m = fmaxf(fmaxf(a, b), c);
-  if (m == -INFINITY) return -INFINITY;
-  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+#define NEG_INF_D (-(double)INFINITY)
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+  const double m = fmax(fmax(a, b), c);
+  if (m == NEG_INF_D) return NEG_INF_D;
+  return m + log(exp(a - m) + exp(b - m) + exp(c - m));
 }
-__device__ __forceinline__ float lse2(float a, float b) {
-  const float m = fmaxf(a, b);
-  if (m == -INFINITY) return -INFINITY;
-  return m + logf(expf(a - m) + expf(b - m));
+__device__ __forceinline__ double lse2(double a, double b) {
+  const double m = fmax(a, b);
+  if (m == NEG_INF_D) return NEG_INF_D;
+  return m + log(exp(a - m) + exp(b - m));
 }
 
 // one wave per row
@@ -64,9 +70,9 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 __global__ __launch_bounds__(CTC_MAX_S) void ctc_alpha_beta_kernel(const float* __restrict__ lp, int ld_t, int ld_n,
                                                                     const int* __restrict__ targets, const long long* __restrict__ tg_off,
                                                                     const int* __restrict__ in_len, const int* __restrict__ tg_len, int T,
-                                                                    int blank, float* __restrict__ alpha, float* __restrict__ beta,
-                                                                    float* __restrict__ nll, int S_max) {
-  __shared__ float prev[2][CTC_MAX_S + 2];
+                                                                    int blank, double* __restrict__ alpha, double* __restrict__ beta,
+                                                                    float* __restrict__ nll, double* __restrict__ nll64, int S_max) {
+  __shared__ double prev[2][CTC_MAX_S + 2];
   const int n = blockIdx.x;
   const bool is_beta = blockIdx.y == 1;
   const int s = threadIdx.x;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(CTC_MAX_S) void ctc_alpha_beta_kernel(const float* 
   const int S = 2 * L + 1;
   const int* tg = targets + tg_off[n];
   const float* lpn = lp + (size_t)n * ld_n;
-  float* out = (is_beta ? beta : alpha) + (size_t)n * T * S_max;
+  double* out = (is_beta ? beta : alpha) + (size_t)n * T * S_max;
 
   int ch = blank;      // l'_s
   bool skip = false;   // alpha: may come from s-2 ; beta: may go to s+2
@@ -85,45 +91,48 @@ __global__ __launch_bounds__(CTC_MAX_S) void ctc_alpha_beta_kernel(const float* 
     else skip = (s + 2 < S) && (tg[(s >> 1) + 1] != ch);
   }
   if (Tn <= 0 || S > S_max) {  // degenerate / longer than the caller sized for: infeasible
-    if (!is_beta && s == 0) nll[n] = INFINITY;
+    if (!is_beta && s == 0) {
+      nll[n] = INFINITY;
+      nll64[n] = (double)INFINITY;
+    }
     return;
   }
 
   // prev rows are padded by 2 on the side the recursion reaches into
-  float cur = -INFINITY;
+  double cur = NEG_INF_D;
   if (!is_beta) {
-    if (s == 0) cur = lpn[blank];
-    else if (s == 1 && S > 1) cur = lpn[ch];
+    if (s == 0) cur = (double)lpn[blank];
+    else if (s == 1 && S > 1) cur = (double)lpn[ch];
   } else {
     const float* lpt = lpn + (size_t)(Tn - 1) * ld_t;
-    if (s == S - 1) cur = lpt[blank];
-    else if (s == S - 2 && S > 1) cur = lpt[ch];
+    if (s == S - 1) cur = (double)lpt[blank];
+    else if (s == S - 2 && S > 1) cur = (double)lpt[ch];
   }
   int buf = 0;
   if (s < 2) {
-    prev[0][is_beta ? CTC_MAX_S + s : s] = -INFINITY;  // padding cells
-    prev[1][is_beta ? CTC_MAX_S + s : s] = -INFINITY;
+    prev[0][is_beta ? CTC_MAX_S + s : s] = NEG_INF_D;  // padding cells
+    prev[1][is_beta ? CTC_MAX_S + s : s] = NEG_INF_D;
   }
   // storage index: alpha uses prev[.][s+2] (reads s+1, s), beta uses prev[.][s] (reads s+1, s+2)
   const int off = is_beta ? 0 : 2;
   if (s < S) out[(size_t)(is_beta ? Tn - 1 : 0) * S_max + s] = cur;
-  prev[buf][s + off] = (s < S) ? cur : -INFINITY;
+  prev[buf][s + off] = (s < S) ? cur : NEG_INF_D;
   __syncthreads();
   for (int step = 1; step < Tn; ++step) {
     const int t = is_beta ? Tn - 1 - step : step;
-    float v = -INFINITY;
+    double v = NEG_INF_D;
     if (s < S) {
-      float a0, a1, a2;
+      double a0, a1, a2;
       if (!is_beta) {
         a0 = prev[buf][s + 2];
         a1 = prev[buf][s + 1];
-        a2 = skip ? prev[buf][s] : -INFINITY;
+        a2 = skip ? prev[buf][s] : NEG_INF_D;
       } else {
         a0 = prev[buf][s];
-        a1 = (s + 1 < S) ? prev[buf][s + 1] : -INFINITY;
-        a2 = skip ? prev[buf][s + 2] : -INFINITY;
+        a1 = (s + 1 < S) ? prev[buf][s + 1] : NEG_INF_D;
+        a2 = skip ? prev[buf][s + 2] : NEG_INF_D;
       }
-      v = lse3(a0, a1, a2) + lpn[(size_t)t * ld_t + ch];
+      v = lse3(a0, a1, a2) + (double)lpn[(size_t)t * ld_t + ch];
       out[(size_t)t * S_max + s] = v;
     }
     buf ^= 1;
@@ -133,9 +142,11 @@ __global__ __launch_bounds__(CTC_MAX_S) void ctc_alpha_beta_kernel(const float* 
   if (!is_beta) {
     // prev[buf] holds alpha_{Tn-1}
     if (s == 0) {
-      const float a = prev[buf][(S - 1) + 2];
-      const float b = (S > 1) ? prev[buf][(S - 2) + 2] : -INFINITY;
-      nll[n] = -lse2(a, b);
+      const double a = prev[buf][(S - 1) + 2];
+      const double b = (S > 1) ? prev[buf][(S - 2) + 2] : NEG_INF_D;
+      const double v = -lse2(a, b);
+      nll64[n] = v;
+      nll[n] = (float)v;
     }
   }
 }
@@ -144,10 +155,10 @@ __global__ __launch_bounds__(CTC_MAX_S) void ctc_alpha_beta_kernel(const float* 
 __global__ __launch_bounds__(128) void ctc_grad_kernel(const float* __restrict__ lp, int ld_t, int ld_n, const int* __restrict__ targets,
                                                        const long long* __restrict__ tg_off, const int* __restrict__ in_len,
                                                        const int* __restrict__ tg_len, int T, int C, int blank,
-                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                       const float* __restrict__ nll, const float* __restrict__ grad_out,
+                                                       const double* __restrict__ alpha, const double* __restrict__ beta,
+                                                       const double* __restrict__ nll, const float* __restrict__ grad_out,
                                                        float* __restrict__ grad, int gld_t, int gld_n, int S_max) {
-  __shared__ float ab[CTC_MAX_S];
+  __shared__ double ab[CTC_MAX_S];
   __shared__ int ext[CTC_MAX_S];
   const int n = blockIdx.x, t = blockIdx.y;
   const int L = tg_len[n], Tn = min(in_len[n], T);
@@ -158,26 +169,26 @@ __global__ __launch_bounds__(128) void ctc_grad_kernel(const float* __restrict__
     return;
   }
   const int* tg = targets + tg_off[n];
-  const float* al = alpha + ((size_t)n * T + t) * S_max;
-  const float* be = beta + ((size_t)n * T + t) * S_max;
+  const double* al = alpha + ((size_t)n * T + t) * S_max;
+  const double* be = beta + ((size_t)n * T + t) * S_max;
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     ab[s] = al[s] + be[s];
     ext[s] = (s & 1) ? tg[s >> 1] : blank;
   }
   __syncthreads();
-  const float nl = nll[n];
-  const float go = grad_out[n];
+  const double nl = nll[n];
+  const double go = (double)grad_out[n];
   const float* lpr = lp + (size_t)n * ld_n + (size_t)t * ld_t;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float res = -INFINITY;
+    double res = NEG_INF_D;
     for (int s = 0; s < S; ++s)
       if (ext[s] == c) res = lse2(res, ab[s]);
-    const float l = lpr[c];
-    grow[c] = (expf(l) - expf(res + nl - l)) * go;
+    const double l = (double)lpr[c];
+    grow[c] = (float)((exp(l) - exp(res + nl - l)) * go);
   }
 }
 
-__global__ void ctc_reduce_kernel(const float* __restrict__ nll, const int* __restrict__ tg_len, int N, int reduction, float scale_in,
+__global__ void ctc_reduce_kernel(const double* __restrict__ nll, const int* __restrict__ tg_len, int N, int reduction, float scale_in,
                                   float* __restrict__ loss, float* __restrict__ grad_out) {
   // reduction 1 = mean: loss = mean_n(nll_n / max(len_n,1)), grad_out_n = scale_in / (N * max(len_n,1))
   // reduction 0 = none: grad_out_n = scale_in (caller multiplies by its own upstream gradient)
@@ -186,10 +197,10 @@ __global__ void ctc_reduce_kernel(const float* __restrict__ nll, const int* __re
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     const float tl = (float)max(tg_len[n], 1);
     if (reduction == 1) {
-      acc += (double)(nll[n] / tl);
+      acc += nll[n] / (double)tl;
       grad_out[n] = scale_in / ((float)N * tl);
     } else {
-      acc += (double)nll[n];
+      acc += nll[n];
       grad_out[n] = scale_in;
     }
   }
@@ -222,7 +233,7 @@ extern "C" int qea_log_softmax_bwd(const float* g, int32_t ldg, const float* lp,
 
 extern "C" size_t qea_ctc_workspace_bytes(int32_t T, int32_t N, int32_t S_max) {
   if (T <= 0 || N <= 0 || S_max <= 0) return 0;
-  return (size_t)2 * N * T * S_max * sizeof(float) + (size_t)N * sizeof(float);
+  return (size_t)2 * N * T * S_max * sizeof(double) + (size_t)N * sizeof(double) + (size_t)N * sizeof(float);
 }
 
 extern "C" int qea_ctc_loss(const float* lp, int32_t ld_t, int32_t ld_n, const int32_t* targets, const int64_t* target_offsets,
@@ -235,16 +246,17 @@ extern "C" int qea_ctc_loss(const float* lp, int32_t ld_t, int32_t ld_n, const i
               (CTC_MAX_S - 1) / 2);
   QEA_REQUIRE(workspace && workspace_bytes >= qea_ctc_workspace_bytes(T, N, S_max), "qea_ctc_loss: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  float* alpha = (float*)workspace;
-  float* beta = alpha + (size_t)N * T * S_max;
-  float* gout = beta + (size_t)N * T * S_max;
+  double* alpha = (double*)workspace;
+  double* beta = alpha + (size_t)N * T * S_max;
+  double* nll64 = beta + (size_t)N * T * S_max;
+  float* gout = (float*)(nll64 + N);
   const int threads = ((S_max + 63) / 64) * 64;
   hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(N, grad ? 2 : 1), dim3(threads), 0, s, lp, ld_t, ld_n, targets,
-                     (const long long*)target_offsets, input_lengths, target_lengths, T, blank, alpha, beta, nll, S_max);
-  hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, s, (const float*)nll, target_lengths, N, reduction, grad_scale, loss, gout);
+                     (const long long*)target_offsets, input_lengths, target_lengths, T, blank, alpha, beta, nll, nll64, S_max);
+  hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)nll64, target_lengths, N, reduction, grad_scale, loss, gout);
   if (grad) {
     hipLaunchKernelGGL(ctc_grad_kernel, dim3(N, T), dim3(128), 0, s, lp, ld_t, ld_n, targets, (const long long*)target_offsets, input_lengths,
-                       target_lengths, T, C, blank, (const float*)alpha, (const float*)beta, (const float*)nll, (const float*)gout, grad,
+                       target_lengths, T, C, blank, (const double*)alpha, (const double*)beta, (const double*)nll64, (const float*)gout, grad,
                        gld_t, gld_n, S_max);
   }
   QEA_CHECK_LAUNCH();

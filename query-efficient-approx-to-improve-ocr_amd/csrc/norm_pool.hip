@@ -40,7 +40,8 @@ template <int MODE>
 __global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ a,
                                                                   int lda, const float* __restrict__ y, int ldy,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                  long long M, int C, int rows_per_block, int rt_n, double* __restrict__ ws) {
+                                                                  const double* __restrict__ stat64, long long M, int C,
+                                                                  int rows_per_block, int rt_n, double* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) double sred[];  // [rt_n][cols*4][2]
   const int cols = C / 4;
   const int ct = threadIdx.x % cols, rt = threadIdx.x / cols;
@@ -49,10 +50,13 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __r
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+    double mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
     if (MODE == 1) {
-      mu = *reinterpret_cast<const f32x4*>(mean + ct * 4);
-      is = *reinterpret_cast<const f32x4*>(invstd + ct * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mu[k] = stat64 ? stat64[ct * 4 + k] : (double)mean[ct * 4 + k];
+        is[k] = stat64 ? stat64[C + ct * 4 + k] : (double)invstd[ct * 4 + k];
+      }
     }
     for (long long r = r0 + rt; r < r1; r += rt_n) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + ct * 4);
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           s0[k] += (double)dz[k];
-          s1[k] += (double)dz[k] * (double)((yv[k] - mu[k]) * is[k]);
+          s1[k] += (double)dz[k] * (((double)yv[k] - mu[k]) * is[k]);
         }
       } else {
 #pragma unroll
@@ -102,7 +106,8 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __r
 
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ ws, int nblk, int C, long long M, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, float eps, float momentum, float* running_mean,
-                                         float* running_var, float* mean_out, float* invstd_out, float* scale_out, float* shift_out) {
+                                         float* running_var, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
+                                         double* stat64) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0, q = 0;
@@ -113,7 +118,12 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ ws, int nblk
   const double mean = s / (double)M;
   double var = q / (double)M - mean * mean;  // biased (normalisation)
   if (var < 0) var = 0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const double invstd_d = 1.0 / sqrt(var + (double)eps);
+  if (stat64) {
+    stat64[c] = mean;
+    stat64[C + c] = invstd_d;
+  }
+  const float invstd = (float)invstd_d;
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   mean_out[c] = (float)mean;
   invstd_out[c] = invstd;
@@ -149,8 +159,8 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ ws, int nblk, 
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, int C, long long M, const float* __restrict__ gamma,
-                                       const float* __restrict__ invstd, int training, float* dgamma, float* dbeta, int accumulate,
-                                       float* k0, float* k1, float* k2) {
+                                       const float* __restrict__ invstd, const double* __restrict__ stat64, int training, float* dgamma,
+                                       float* dbeta, int accumulate, double* k0, double* k1, double* k2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0, q = 0;
@@ -161,9 +171,9 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, 
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
   const float g = gamma ? gamma[c] : 1.f;
-  k0[c] = g * invstd[c];                           // dy = k0 * (dz - k1 - xhat * k2)
-  k1[c] = training ? (float)(s / (double)M) : 0.f;
-  k2[c] = training ? (float)(q / (double)M) : 0.f;
+  k0[c] = (double)g * (stat64 ? stat64[C + c] : (double)invstd[c]);  // dy = k0 * (dz - k1 - xhat * k2)
+  k1[c] = training ? s / (double)M : 0.0;
+  k2[c] = training ? q / (double)M : 0.0;
 }
 
 // ------------------------------------------------------------------ elementwise
@@ -189,8 +199,12 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, int ldy, float* __r
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ a, int lda,
                                     const float* __restrict__ y, int ldy, float* __restrict__ dy, int lddy, long long M, int C,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k0,
-                                    const float* __restrict__ k1, const float* __restrict__ k2) {
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, const double* __restrict__ stat64,
+                                    const double* __restrict__ k0, const double* __restrict__ k1, const double* __restrict__ k2) {
+  // fp64 arithmetic with fp64 per-channel constants: mean(dz), mean(dz*xhat), mean and invstd are
+  // common to all pixels of a channel, so rounding them to fp32 puts a CORRELATED error into dy
+  // which the per-channel sums of the next layer amplify by the pixel count (measured 7e-4 on
+  // dbeta at M = 8192); ATen's CPU kernel also runs this in its fp64 accumulate type.
   const int cols = C / 4;
   const long long n = M * cols;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -203,14 +217,14 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, cons
       for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
     }
     const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ct * 4);
-    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + ct * 4);
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(k0 + ct * 4);
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(k1 + ct * 4);
-    const f32x4 c2 = *reinterpret_cast<const f32x4*>(k2 + ct * 4);
     f32x4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = c0[k] * (dz[k] - c1[k] - (yv[k] - mu[k]) * is[k] * c2[k]);
+    for (int k = 0; k < 4; ++k) {
+      const int c = ct * 4 + k;
+      const double mu = stat64 ? stat64[c] : (double)mean[c];
+      const double is = stat64 ? stat64[C + c] : (double)invstd[c];
+      o[k] = (float)(k0[c] * ((double)dz[k] - k1[c] - ((double)yv[k] - mu) * is * k2[c]));
+    }
     *reinterpret_cast<f32x4*>(dy + r * lddy + ct * 4) = o;
   }
 }
@@ -328,12 +342,13 @@ int check_nc(const char* who, long long M, int C, size_t ws_bytes, void* ws, con
 extern "C" size_t qea_colreduce_workspace_bytes(int64_t M, int32_t C) {
   if (M <= 0 || C <= 0 || C % 4) return 0;
   const ColGeom g = col_geom(M, C);
-  return (size_t)g.grid * C * 2 * sizeof(double) + 3 * (size_t)C * sizeof(float);
+  return (size_t)g.grid * C * 2 * sizeof(double) + 3 * (size_t)C * sizeof(double);
 }
 
 extern "C" int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* beta, float eps,
                                   float momentum, float* running_mean, float* running_var, float* mean_out, float* invstd_out,
-                                  float* scale_out, float* shift_out, void* workspace, size_t workspace_bytes, void* stream) {
+                                  float* scale_out, float* shift_out, double* stat64, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
   QEA_REQUIRE(y && mean_out && invstd_out && scale_out && shift_out, "qea_bn_train_stats: null pointer");
   const ColGeom g = col_geom(M, C);
   int rc = check_nc("qea_bn_train_stats", M, C, workspace_bytes, workspace, g);
@@ -342,9 +357,10 @@ extern "C" int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
   hipLaunchKernelGGL(colreduce_kernel<0>, dim3(g.grid), dim3(RED_THREADS), lds, s, y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                     (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
+                     nullptr, (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, g.grid, C,
-                     (long long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
+                     (long long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out,
+                     stat64);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
@@ -369,9 +385,9 @@ extern "C" int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, 
 }
 
 extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* y, int32_t ldy, int64_t M, int32_t C,
-                          const float* gamma, const float* mean, const float* invstd, int32_t training, float* dgamma, float* dbeta,
-                          int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+                          const float* gamma, const float* mean, const float* invstd, const double* stat64, int32_t training,
+                          float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   QEA_REQUIRE(da && y && mean && invstd && dy, "qea_bn_bwd: null pointer");
   const ColGeom g = col_geom(M, C);
   int rc = check_nc("qea_bn_bwd", M, C, workspace_bytes, workspace, g);
@@ -380,16 +396,16 @@ extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t
   QEA_REQUIRE(ldda % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!a || lda % 4 == 0), "qea_bn_bwd: strides must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
   double* ws = (double*)workspace;
-  float* k0 = (float*)(ws + (size_t)g.grid * C * 2);
-  float* k1 = k0 + C;
-  float* k2 = k1 + C;
+  double* k0 = ws + (size_t)g.grid * C * 2;
+  double* k1 = k0 + C;
+  double* k2 = k1 + C;
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
-  hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.grid), dim3(RED_THREADS), lds, s, da, ldda, a, lda, y, ldy, mean, invstd, (long long)M, C,
-                     g.rows_per_block, g.rt, ws);
+  hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.grid), dim3(RED_THREADS), lds, s, da, ldda, a, lda, y, ldy, mean, invstd, stat64,
+                     (long long)M, C, g.rows_per_block, g.rt, ws);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)ws, g.grid, C, (long long)M, gamma,
-                     invstd, training, dgamma, dbeta, accumulate_param_grads, k0, k1, k2);
+                     invstd, stat64, training, dgamma, dbeta, accumulate_param_grads, k0, k1, k2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, s, da, ldda, a, lda, y, ldy, dy, lddy, (long long)M, C,
-                     mean, invstd, (const float*)k0, (const float*)k1, (const float*)k2);
+                     mean, invstd, stat64, (const double*)k0, (const double*)k1, (const double*)k2);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
@@ -404,7 +420,7 @@ extern "C" int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, flo
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
   hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.grid), dim3(RED_THREADS), lds, s, x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                     (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
+                     nullptr, (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, g.grid, C, out, accumulate);
   QEA_CHECK_LAUNCH();
   return QEA_OK;

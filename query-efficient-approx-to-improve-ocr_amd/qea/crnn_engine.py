@@ -1,0 +1,266 @@
+"""CRNN proxy on the HIP library: explicit forward / backward kernel schedules.
+
+Mirrors reference models/model_crnn.py:16-28 (CRNN.forward), :47-56 (Convolutional.forward) and
+their autograd, including the NaN scrub of CRNN.backward_hook (:30-32).
+
+  x [B,1,32,W] -> conv1..conv7 (NHWC, bias/ReLU fused in the GEMM epilogue, pools as separate
+  HBM passes) -> conv7 writes straight into the [T,B,512] sequence layout (map_to_sequence)
+  -> 2 x bidirectional LSTM (input projection = one GEMM per direction, recurrence = fused
+  MFMA step kernel) -> Linear (GEMM, vocab padded to 96 columns) -> log_softmax.
+"""
+import torch
+
+from . import ops
+from .params import ensure_flat
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+HID = 256
+
+# (name, cin, cout, relu fused in the conv epilogue, pool after (kh,kw) or None)
+CONVS = (("conv2", 64, 128, True, (2, 2)), ("conv3", 128, 256, True, None), ("conv4", 256, 256, True, (2, 1)))
+
+
+class CRNNEngine:
+    def __init__(self, module, vocab):
+        self.m = module
+        self.vocab = vocab
+        self.vpad = (vocab + 31) // 32 * 32
+        # `convo.module.` when the backbone sits in the (never used) nn.DataParallel wrapper
+        self.cp = "convo.module." if any(n.startswith("convo.module.") for n, _ in module.named_parameters()) else "convo."
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, bn_training, need_grad):
+        fs = ensure_flat(self.m)
+        P = dict(self.m.named_parameters())
+        Bf = dict(self.m.named_buffers())
+        dev = x.device
+        B, _, H, W = x.shape
+        if H != 32 or W % 4:
+            raise ValueError(f"CRNN input must be [B,1,32,W] with W % 4 == 0, got {H}x{W}")
+        c = self.cp
+        ctx = {"x": x, "B": B, "H": H, "W": W, "bn_training": bn_training} if need_grad else None
+
+        # conv1 (C_in = 1) + ReLU, pool 2x2
+        a1 = torch.empty(B * H * W, 64, device=dev)
+        ops.conv_c1_fwd(x, P[c + "conv1.weight"], P[c + "conv1.bias"], a1, 64, B, H, W, 64, relu=True)
+        h, w = H // 2, W // 2
+        p1 = torch.empty(B * h * w, 64, device=dev)
+        ops.maxpool_fwd(a1, 64, p1, 64, B, H, W, 64, 2, 2)
+        acts = {"a1": a1, "p1": p1}
+        cur, ccur = p1, 64
+        dims = {"conv1": (H, W)}
+        for name, cin, cout, relu, pool in CONVS:
+            a = torch.empty(B * h * w, cout, device=dev)
+            ops.conv_igemm(cur, P[c + name + ".weight"], a, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1),
+                           ldx=cin, ldy=cout, bias=P[c + name + ".bias"], relu=relu)
+            acts["a" + name[-1]] = a
+            dims[name] = (h, w)
+            cur, ccur = a, cout
+            if pool:
+                ph, pw = h // pool[0], w // pool[1]
+                pt = torch.empty(B * ph * pw, cout, device=dev)
+                ops.maxpool_fwd(a, cout, pt, cout, B, h, w, cout, pool[0], pool[1])
+                acts["p" + name[-1]] = pt
+                cur = pt
+                h, w = ph, pw
+        # conv5 + BN1 + ReLU, conv6 + BN2 + ReLU (bias stays in the conv: y = conv + b is what BN sees)
+        for name, bn, cin in (("conv5", "batchnorm1", 256), ("conv6", "batchnorm2", 512)):
+            M = B * h * w
+            y = torch.empty(M, 512, device=dev)
+            ops.conv_igemm(cur, P[c + name + ".weight"], y, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=512, KH=3, KW=3, pad=(1, 1),
+                           ldx=cin, ldy=512, bias=P[c + name + ".bias"])
+            coef = torch.empty(4, 512, device=dev)
+            stat64 = None
+            if bn_training:
+                stat64 = torch.empty(2, 512, device=dev, dtype=torch.float64) if need_grad else None
+                ops.bn_train_stats(y, 512, M, 512, P[c + bn + ".weight"], P[c + bn + ".bias"], BN_EPS, BN_MOMENTUM,
+                                   Bf[c + bn + ".running_mean"], Bf[c + bn + ".running_var"], coef[0], coef[1], coef[2], coef[3], stat64)
+            else:
+                ops.bn_eval_coeff(512, P[c + bn + ".weight"], P[c + bn + ".bias"], Bf[c + bn + ".running_mean"],
+                                  Bf[c + bn + ".running_var"], BN_EPS, None, coef[0], coef[1], coef[2], coef[3])
+            a = torch.empty(M, 512, device=dev)
+            ops.bn_apply(y, 512, a, 512, M, 512, coef[2], coef[3], relu=True)
+            acts["y" + name[-1]], acts["coef" + name[-1]], acts["a" + name[-1]], acts["st" + name[-1]] = y, coef, a, stat64
+            dims[name] = (h, w)
+            cur = a
+        if bn_training:
+            fs.ibuf.add_(1)
+        p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
+        ops.maxpool_fwd(cur, 512, p6, 512, B, h, w, 512, 2, 1)
+        acts["p6"] = p6
+        h6, w6 = h // 2, w
+        T = w6 - 1
+        if h6 != 2:
+            raise ValueError("CRNN backbone must reduce the height to 2 before conv7")
+        # conv7 2x2 pad 0 -> [B,1,T,512], written as [T][B][512]
+        seq = torch.empty(T, B, 512, device=dev)
+        ops.conv_igemm(p6, P[c + "conv7.weight"], seq, B=B, H=h6, W=w6, Cin=512, OH=1, OW=T, N=512, KH=2, KW=2, ldx=512, ldy=512,
+                       bias=P[c + "conv7.bias"], out_mode=ops.OUT_TBC)
+        dims["conv7"] = (h6, w6)
+
+        # BiLSTM x2
+        xin = seq
+        lstm = []
+        for layer in (0, 1):
+            gates = torch.empty(T, B, 2 * 4 * HID, device=dev)
+            pf = torch.empty(2, 4 * HID * HID, device=dev)
+            pb = torch.empty(2, 4 * HID * HID, device=dev) if need_grad else None
+            for d, suf in enumerate(("", "_reverse")):
+                bias = P[f"lstm.bias_ih_l{layer}{suf}"] + P[f"lstm.bias_hh_l{layer}{suf}"]
+                ops.conv_igemm(xin, P[f"lstm.weight_ih_l{layer}{suf}"], gates[:, :, d * 4 * HID:], B=1, H=1, W=T * B, Cin=512, OH=1,
+                               OW=T * B, N=4 * HID, KH=1, KW=1, ldx=512, ldy=2 * 4 * HID, bias=bias)
+                ops.lstm_pack_whh(P[f"lstm.weight_hh_l{layer}{suf}"], pf[d], pb[d] if need_grad else None)
+            cst = torch.empty(T, B, 2 * HID, device=dev)
+            y = torch.empty(T, B, 2 * HID, device=dev)
+            ops.lstm_layer_fwd(gates, cst, y, pf, T, B)
+            lstm.append({"x": xin, "gates": gates, "c": cst, "y": y, "pb": pb})
+            xin = y
+        # Linear + log_softmax (vocab padded to a multiple of 32 columns; pad columns stay 0)
+        vp = self.vpad
+        logits = torch.zeros(T * B, vp, device=dev)
+        ops.conv_igemm(xin, P["linear.weight"], logits, B=1, H=1, W=T * B, Cin=512, OH=1, OW=T * B, N=self.vocab, KH=1, KW=1, ldx=512,
+                       ldy=vp, bias=P["linear.bias"])
+        lp = torch.zeros(T * B, vp, device=dev)
+        ops.log_softmax_fwd(logits, vp, lp, vp, T * B, self.vocab)
+        out = lp.view(T, B, vp)[:, :, :self.vocab]
+        if need_grad:
+            ctx.update(acts=acts, dims=dims, lstm=lstm, lp=lp, T=T, h6=h6, w6=w6)
+        return out, ctx
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, dlp, nan_scrub, need_dx, param_grads=True):
+        """dlp: gradient w.r.t. the returned log-probs [T,B,vocab].  Returns dx [B,1,H,W] or None."""
+        fs = ensure_flat(self.m)
+        fs.attach_grads()
+        P = dict(self.m.named_parameters())
+        G = {n: p.grad for n, p in P.items()}
+        dev = dlp.device
+        B, H, W, T = ctx["B"], ctx["H"], ctx["W"], ctx["T"]
+        acts, dims = ctx["acts"], ctx["dims"]
+        vp, V = self.vpad, self.vocab
+        c = self.cp
+        TB = T * B
+
+        g = dlp.contiguous().view(TB, V)
+        dlogits = torch.empty(TB, vp, device=dev)
+        ops.log_softmax_bwd(g, V, ctx["lp"], vp, dlogits, vp, TB, V, vp, nan_scrub)
+
+        # Linear
+        y1 = ctx["lstm"][1]["y"]
+        if param_grads:
+            dwl = torch.empty(vp, 512, device=dev)
+            ops.conv_wgrad(dlogits, y1, dwl, B=1, PH=1, PW=TB, QH=1, QW=TB, R=vp, Cc=512, KH=1, KW=1, ldp=vp, ldq=512)
+            G["linear.weight"].add_(dwl[:V])
+            dbl = torch.empty(vp, device=dev)
+            ops.colsum(dlogits, vp, TB, vp, dbl)
+            G["linear.bias"].add_(dbl[:V])
+        wpad = torch.zeros(vp, 512, device=dev)
+        wpad[:V].copy_(P["linear.weight"])
+        wlT = torch.empty(512, vp, device=dev)
+        ops.transpose2d(wpad, wlT, vp, 512)
+        dy = torch.empty(T, B, 512, device=dev)
+        ops.conv_igemm(dlogits, wlT, dy, B=1, H=1, W=TB, Cin=vp, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=vp, ldy=512)
+
+        # BiLSTM layers, top first
+        dseq_bt = None
+        for layer in (1, 0):
+            s = ctx["lstm"][layer]
+            gates, cst, yl, xin = s["gates"], s["c"], s["y"], s["x"]
+            dc = torch.empty(B, 2 * HID, device=dev)
+            ops.lstm_layer_bwd(gates, cst, dy, s["pb"], dc, T, B)          # gates now hold dgates
+            if param_grads:
+                for d, suf in enumerate(("", "_reverse")):
+                    dg = gates[:, :, d * 4 * HID:]
+                    ops.conv_wgrad(dg, xin, G[f"lstm.weight_ih_l{layer}{suf}"], B=1, PH=1, PW=TB, QH=1, QW=TB, R=4 * HID, Cc=512,
+                                   KH=1, KW=1, ldp=8 * HID, ldq=512, accumulate=True)
+                    ops.colsum(dg, 8 * HID, TB, 4 * HID, G[f"lstm.bias_ih_l{layer}{suf}"], accumulate=True)
+                    ops.colsum(dg, 8 * HID, TB, 4 * HID, G[f"lstm.bias_hh_l{layer}{suf}"], accumulate=True)
+                    if T > 1:
+                        n = (T - 1) * B
+                        if d == 0:
+                            pg, qh = gates[1:, :, :4 * HID], yl[:T - 1, :, :HID]
+                        else:
+                            pg, qh = gates[:T - 1, :, 4 * HID:], yl[1:, :, HID:]
+                        ops.conv_wgrad(pg, qh, G[f"lstm.weight_hh_l{layer}{suf}"], B=1, PH=1, PW=n, QH=1, QW=n, R=4 * HID, Cc=HID,
+                                       KH=1, KW=1, ldp=8 * HID, ldq=2 * HID, accumulate=True)
+            wcat = torch.cat((P[f"lstm.weight_ih_l{layer}"], P[f"lstm.weight_ih_l{layer}_reverse"]), 0)   # [2048][512]
+            wT = torch.empty(512, 8 * HID, device=dev)
+            ops.transpose2d(wcat, wT, 8 * HID, 512)
+            if layer == 1:
+                dxl = torch.empty(T, B, 512, device=dev)
+                ops.conv_igemm(gates, wT, dxl, B=1, H=1, W=TB, Cin=8 * HID, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512)
+                dy = dxl
+            else:
+                # rows (t,b) -> output row b*T + t : the gradient of conv7's output in its own [B,1,T,512] order
+                dseq_bt = torch.empty(B, T, 512, device=dev)
+                ops.conv_igemm(gates, wT, dseq_bt, B=T, H=1, W=B, Cin=8 * HID, OH=1, OW=B, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512,
+                               out_mode=ops.OUT_TBC)
+
+        # conv7 (2x2, pad 0) backward
+        h6, w6 = ctx["h6"], ctx["w6"]
+        p6 = acts["p6"]
+        if param_grads:
+            ops.colsum(dseq_bt, 512, B * T, 512, G[c + "conv7.bias"], accumulate=True)
+            ops.conv_wgrad(dseq_bt, p6, G[c + "conv7.weight"], B=B, PH=1, PW=T, QH=h6, QW=w6, R=512, Cc=512, KH=2, KW=2, ldp=512, ldq=512,
+                           accumulate=True)
+        w7t = torch.empty(512, 2, 2, 512, device=dev)
+        ops.filter_flip_transpose(P[c + "conv7.weight"], w7t, 512, 512, 2, 2)
+        dp6 = torch.empty(B * h6 * w6, 512, device=dev)
+        ops.conv_igemm(dseq_bt, w7t, dp6, B=B, H=1, W=T, Cin=512, OH=h6, OW=w6, N=512, KH=2, KW=2, pad=(1, 1), ldx=512, ldy=512)
+        # pool (2,1) backward -> grad of a6 (ReLU handled by bn_bwd's mask)
+        h, w = dims["conv6"]
+        da = torch.empty(B * h * w, 512, device=dev)
+        ops.maxpool_bwd(acts["a6"], 512, dp6, 512, da, 512, B, h, w, 512, 2, 1, relu_mask=False)
+        bn_training = ctx["bn_training"]
+        for name, bn, cin, src in (("conv6", "batchnorm2", 512, "a5"), ("conv5", "batchnorm1", 256, "p4")):
+            M = B * h * w
+            k = name[-1]
+            coef = acts["coef" + k]
+            dy_ = torch.empty(M, 512, device=dev)
+            ops.bn_bwd(da, 512, acts["a" + k], 512, acts["y" + k], 512, M, 512, P[c + bn + ".weight"], coef[0], coef[1], bn_training,
+                       G[c + bn + ".weight"] if param_grads else None, G[c + bn + ".bias"] if param_grads else None, dy_, 512,
+                       accumulate=True, stat64=acts["st" + k])
+            if param_grads:
+                ops.colsum(dy_, 512, M, 512, G[c + name + ".bias"], accumulate=True)
+                ops.conv_wgrad(dy_, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=512, Cc=cin, KH=3, KW=3,
+                               pad=(1, 1), ldp=512, ldq=cin, accumulate=True)
+            wt = torch.empty(cin, 3, 3, 512, device=dev)
+            ops.filter_flip_transpose(P[c + name + ".weight"], wt, 512, cin, 3, 3)
+            da = torch.empty(M, cin, device=dev)
+            ops.conv_igemm(dy_, wt, da, B=B, H=h, W=w, Cin=512, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=512, ldy=cin)
+        # da = grad of p4 [B,4,W/4,256]
+        # conv4 (+ReLU, pool (2,1)), conv3 (+ReLU), conv2 (+ReLU, pool (2,2))
+        dcur = da
+        for name, cin, cout, relu, pool in reversed(CONVS):
+            h, w = dims[name]
+            M = B * h * w
+            a = acts["a" + name[-1]]
+            if pool:
+                dyc = torch.empty(M, cout, device=dev)
+                ops.maxpool_bwd(a, cout, dcur, cout, dyc, cout, B, h, w, cout, pool[0], pool[1], relu_mask=True)
+            else:
+                dyc = dcur                                  # already masked by the producer's epilogue
+            src = {"conv4": "a3", "conv3": "p2", "conv2": "p1"}[name]
+            if param_grads:
+                ops.colsum(dyc, cout, M, cout, G[c + name + ".bias"], accumulate=True)
+                ops.conv_wgrad(dyc, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
+                               pad=(1, 1), ldp=cout, ldq=cin, accumulate=True)
+            wt = torch.empty(cin, 3, 3, cout, device=dev)
+            ops.filter_flip_transpose(P[c + name + ".weight"], wt, cout, cin, 3, 3)
+            dnext = torch.empty(M, cin, device=dev)
+            # conv4's input a3 is a bare ReLU output (no pool in between): fuse its mask here
+            mask = acts["a3"] if name == "conv4" else None
+            ops.conv_igemm(dyc, wt, dnext, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cin,
+                           mask=mask, ldmask=cin if mask is not None else 0)
+            dcur = dnext
+        # dcur = grad of p1 [B,16,W/2,64]; conv1
+        dy1 = torch.empty(B * H * W, 64, device=dev)
+        ops.maxpool_bwd(acts["a1"], 64, dcur, 64, dy1, 64, B, H, W, 64, 2, 2, relu_mask=True)
+        if param_grads:
+            ops.conv_c1_wgrad(ctx["x"], dy1, 64, G[c + "conv1.weight"], G[c + "conv1.bias"], B, H, W, 64, accumulate=True)
+        if not need_dx:
+            return None
+        dx = torch.empty(B, 1, H, W, device=dev)
+        ops.conv_c1_dgrad(dy1, 64, P[c + "conv1.weight"], dx, B, H, W, 64)
+        return dx

@@ -85,11 +85,11 @@ def _colws(M, C_, device):
     return ws.data_ptr(), ws.numel()
 
 
-def bn_train_stats(y, ldy, M, C_, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift):
+def bn_train_stats(y, ldy, M, C_, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, stat64=None):
     wp, wn = _colws(M, C_, y.device)
     _lib.check(_lib.lib().qea_bn_train_stats(_ptr(y), ldy, M, C_, _ptr(gamma), _ptr(beta), eps, momentum,
                                              _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
-                                             _ptr(scale), _ptr(shift), wp, wn, _stream()), "qea_bn_train_stats")
+                                             _ptr(scale), _ptr(shift), _ptr(stat64), wp, wn, _stream()), "qea_bn_train_stats")
 
 
 def bn_eval_coeff(C_, gamma, beta, running_mean, running_var, eps, conv_bias, mean, invstd, scale, shift):
@@ -103,11 +103,11 @@ def bn_apply(y, ldy, a, lda, M, C_, scale, shift, relu=True):
                "qea_bn_apply")
 
 
-def bn_bwd(da, ldda, a, lda, y, ldy, M, C_, gamma, mean, invstd, training, dgamma, dbeta, dy, lddy, accumulate=False):
+def bn_bwd(da, ldda, a, lda, y, ldy, M, C_, gamma, mean, invstd, training, dgamma, dbeta, dy, lddy, accumulate=False, stat64=None):
     wp, wn = _colws(M, C_, da.device)
     _lib.check(_lib.lib().qea_bn_bwd(_ptr(da), ldda, _ptr(a), lda, _ptr(y), ldy, M, C_, _ptr(gamma), _ptr(mean),
-                                     _ptr(invstd), int(training), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(dy),
-                                     lddy, wp, wn, _stream()), "qea_bn_bwd")
+                                     _ptr(invstd), _ptr(stat64), int(training), _ptr(dgamma), _ptr(dbeta), int(accumulate),
+                                     _ptr(dy), lddy, wp, wn, _stream()), "qea_bn_bwd")
 
 
 def colsum(x, ldx, M, C_, out, accumulate=False):

@@ -1,0 +1,206 @@
+"""UNet cleaner on the HIP library: explicit forward / backward kernel schedules.
+
+Mirrors reference models/model_unet.py:49-76 (forward) and its autograd.  Everything between
+the [B,1,H,W] input and the [B,1,H,W] sigmoid output stays NHWC in HBM:
+
+  * every conv3x3 of a `_block` (model_unet.py:78-109) is one implicit-GEMM MFMA launch; its
+    BatchNorm is a statistics pass (fp64 sums) + one apply(+ReLU) pass;
+  * a decoder level's torch.cat((up, skip), 1) (model_unet.py:63-74) never copies: the encoder's
+    second BN/ReLU writes its output into channels [c, 2c) of the level's concat buffer and the
+    transposed conv scatters into channels [0, c);
+  * the backward walks the same graph in reverse with dgrad = the same implicit GEMM on
+    flipped/transposed filters, wgrad = the pixel-reduction MFMA kernel, accumulating straight
+    into the flat gradient buffer (qea/params.py).
+"""
+import torch
+
+from . import ops
+from .params import ensure_flat
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class _Block:
+    """Names + channel counts of one conv-BN-ReLU x2 block."""
+
+    def __init__(self, mod, name, cin, cout):
+        self.mod, self.name, self.cin, self.cout = mod, name, cin, cout
+
+    def key(self, i, leaf):
+        kind = "conv" if leaf == "w" else "norm"
+        suffix = {"w": "weight", "gamma": "weight", "beta": "bias", "rm": "running_mean", "rv": "running_var"}[leaf]
+        return f"{self.mod}.{self.name}{kind}{i}.{suffix}"
+
+
+class UNetEngine:
+    def __init__(self, module, features=32):
+        self.m = module
+        f = features
+        self.f = f
+        self.enc = [_Block("encoder1", "enc1", 1, f), _Block("encoder2", "enc2", f, 2 * f), _Block("encoder3", "enc3", 2 * f, 4 * f),
+                    _Block("encoder4", "enc4", 4 * f, 8 * f)]
+        self.bott = _Block("bottleneck", "bottleneck", 8 * f, 16 * f)
+        self.dec = {l: _Block(f"decoder{l}", f"dec{l}", 2 * c, c) for l, c in ((4, 8 * f), (3, 4 * f), (2, 2 * f), (1, f))}
+
+    # ------------------------------------------------------------------ helpers
+    def _tensors(self):
+        P = dict(self.m.named_parameters())
+        Bf = dict(self.m.named_buffers())
+        return P, Bf
+
+    def _conv_bn_relu(self, P, Bf, blk, i, x, ldx, cin, B, H, W, out, ldo, training, saved):
+        """x [B,H,W,cin] (pixel stride ldx) -> conv -> BN -> ReLU -> out (pixel stride ldo)."""
+        dev = x.device
+        cout = blk.cout
+        M = B * H * W
+        w = P[blk.key(i, "w")]
+        y = torch.empty(M, cout, device=dev)
+        if cin == 1:
+            ops.conv_c1_fwd(x, w, None, y, cout, B, H, W, cout, relu=False)
+        else:
+            ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=cout)
+        coef = torch.empty(4, cout, device=dev)  # mean, invstd, scale, shift
+        stat64 = None
+        gamma, beta = P[blk.key(i, "gamma")], P[blk.key(i, "beta")]
+        rm, rv = Bf[blk.key(i, "rm")], Bf[blk.key(i, "rv")]
+        if training:
+            stat64 = torch.empty(2, cout, device=dev, dtype=torch.float64) if saved is not None else None
+            ops.bn_train_stats(y, cout, M, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[0], coef[1], coef[2], coef[3], stat64)
+        else:
+            ops.bn_eval_coeff(cout, gamma, beta, rm, rv, BN_EPS, None, coef[0], coef[1], coef[2], coef[3])
+        ops.bn_apply(y, cout, out, ldo, M, cout, coef[2], coef[3], relu=True)
+        if saved is not None:
+            saved.append((y, coef, stat64))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training, need_grad):
+        """x: [B,1,H,W] contiguous CUDA fp32.  Returns (out [B,1,H,W], ctx or None)."""
+        fs = ensure_flat(self.m)
+        P, Bf = self._tensors()
+        B, _, H, W = x.shape
+        if H % 16 or W % 16:
+            raise ValueError(f"UNet input {H}x{W} must be a multiple of 16 in both dimensions")
+        dev = x.device
+        f = self.f
+        ctx = {"x": x, "B": B, "H": H, "W": W, "training": training, "blocks": {}} if need_grad else None
+
+        def run_block(blk, xin, ldx, cin, h, w, out, ldo):
+            saved = [] if need_grad else None
+            a1 = torch.empty(B * h * w, blk.cout, device=dev)
+            self._conv_bn_relu(P, Bf, blk, 1, xin, ldx, cin, B, h, w, a1, blk.cout, training, saved)
+            self._conv_bn_relu(P, Bf, blk, 2, a1, blk.cout, blk.cout, B, h, w, out, ldo, training, saved)
+            if need_grad:
+                ctx["blocks"][blk.mod] = {"xin": xin, "ldx": ldx, "cin": cin, "h": h, "w": w, "a1": a1, "out": out, "ldo": ldo,
+                                          "y1": saved[0][0], "coef1": saved[0][1], "st1": saved[0][2], "y2": saved[1][0],
+                                          "coef2": saved[1][1], "st2": saved[1][2]}
+
+        # encoder: level l has c = f*2^(l-1) channels at (H,W)/2^(l-1); its output goes to cat_l[:, c:2c]
+        cats = {}
+        xin, ldx, cin = x, 1, 1
+        h, w = H, W
+        for l, blk in enumerate(self.enc, start=1):
+            c = blk.cout
+            cat = torch.empty(B * h * w, 2 * c, device=dev)
+            cats[l] = (cat, h, w, c)
+            skip = cat[:, c:]
+            run_block(blk, xin, ldx, cin, h, w, skip, 2 * c)
+            pooled = torch.empty(B * (h // 2) * (w // 2), c, device=dev)
+            ops.maxpool_fwd(skip, 2 * c, pooled, c, B, h, w, c, 2, 2)
+            xin, ldx, cin = pooled, c, c
+            h, w = h // 2, w // 2
+        d = torch.empty(B * h * w, self.bott.cout, device=dev)
+        run_block(self.bott, xin, ldx, cin, h, w, d, self.bott.cout)
+        dcin = self.bott.cout
+        ups = {}
+        for l in (4, 3, 2, 1):
+            cat, hh, ww, c = cats[l]
+            wup = P[f"upconv{l}.weight"]                       # [2c][2][2][c] physical (IOHW channels_last)
+            wT = torch.empty(4 * c, dcin, device=dev)
+            ops.transpose2d(wup, wT, dcin, 4 * c)
+            ops.conv_igemm(d, wT, cat, B=B, H=h, W=w, Cin=dcin, OH=h, OW=w, N=4 * c, KH=1, KW=1, ldx=dcin, ldy=2 * c,
+                           bias=P[f"upconv{l}.bias"], out_mode=ops.OUT_CONVT)
+            ups[l] = (d, dcin, h, w)
+            h, w = hh, ww
+            dnew = torch.empty(B * h * w, c, device=dev)
+            run_block(self.dec[l], cat, 2 * c, 2 * c, h, w, dnew, c)
+            d, dcin = dnew, c
+        out = torch.empty(B, 1, H, W, device=dev)
+        ops.head_fwd(d, f, P["conv.weight"], P["conv.bias"], out, B * H * W, f)
+        if training:
+            fs.ibuf.add_(1)                                    # all num_batches_tracked counters at once
+        if need_grad:
+            ctx.update(cats=cats, ups=ups, d1=d, out=out)
+        return out, ctx
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, dout):
+        """dout: gradient w.r.t. the sigmoid output [B,1,H,W].  Parameter gradients are accumulated
+        into the flat gradient buffer; returns None (the input image needs no gradient)."""
+        fs = ensure_flat(self.m)
+        fs.attach_grads()
+        P = dict(self.m.named_parameters())
+        G = {n: p.grad for n, p in P.items()}
+        B, H, W = ctx["B"], ctx["H"], ctx["W"]
+        dev = dout.device
+        f = self.f
+        training = ctx["training"]
+        dout = dout.contiguous()
+
+        def block_bwd(blk, da2, ldda):
+            """da2: grad w.r.t. the block output (pixel stride ldda).  Returns grad w.r.t. the block input
+            as a fresh [M][cin] tensor, or None for the first encoder block."""
+            s = ctx["blocks"][blk.mod]
+            h, w, cin, cout = s["h"], s["w"], s["cin"], blk.cout
+            M = B * h * w
+            dy2 = torch.empty(M, cout, device=dev)
+            ops.bn_bwd(da2, ldda, s["out"], s["ldo"], s["y2"], cout, M, cout, P[blk.key(2, "gamma")], s["coef2"][0], s["coef2"][1],
+                       training, G[blk.key(2, "gamma")], G[blk.key(2, "beta")], dy2, cout, accumulate=True, stat64=s["st2"])
+            w2 = P[blk.key(2, "w")]
+            ops.conv_wgrad(dy2, s["a1"], G[blk.key(2, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cout, KH=3, KW=3, pad=(1, 1),
+                           ldp=cout, ldq=cout, accumulate=True)
+            w2t = torch.empty(cout, 3, 3, cout, device=dev)
+            ops.filter_flip_transpose(w2, w2t, cout, cout, 3, 3)
+            da1 = torch.empty(M, cout, device=dev)
+            ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout)
+            dy1 = dy2  # reuse
+            ops.bn_bwd(da1, cout, s["a1"], cout, s["y1"], cout, M, cout, P[blk.key(1, "gamma")], s["coef1"][0], s["coef1"][1],
+                       training, G[blk.key(1, "gamma")], G[blk.key(1, "beta")], dy1, cout, accumulate=True, stat64=s["st1"])
+            if cin == 1:
+                ops.conv_c1_wgrad(s["xin"], dy1, cout, G[blk.key(1, "w")], None, B, h, w, cout, accumulate=True)
+                return None
+            ops.conv_wgrad(dy1, s["xin"], G[blk.key(1, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3, pad=(1, 1),
+                           ldp=cout, ldq=s["ldx"], accumulate=True)
+            w1t = torch.empty(cin, 3, 3, cout, device=dev)
+            ops.filter_flip_transpose(P[blk.key(1, "w")], w1t, cout, cin, 3, 3)
+            dxin = torch.empty(M, cin, device=dev)
+            ops.conv_igemm(dy1, w1t, dxin, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cin)
+            return dxin
+
+        # head
+        d1 = ctx["d1"]
+        M0 = B * H * W
+        dd = torch.empty(M0, f, device=dev)
+        ops.head_bwd(d1, f, ctx["out"], dout, P["conv.weight"], dd, f, G["conv.weight"], G["conv.bias"], M0, f, accumulate=True)
+
+        # decoder levels 1..4: block backward gives d(cat_l); split into up-conv grad and skip grad
+        dcats = {}
+        for l in (1, 2, 3, 4):
+            dcat = block_bwd(self.dec[l], dd, self.dec[l].cout)
+            cat, hh, ww, c = ctx["cats"][l]
+            dcats[l] = dcat
+            dprev, dcin, h, w = ctx["ups"][l]              # input of upconv_l: [B*h*w][dcin]
+            ops.colsum(dcat, 2 * c, B * hh * ww, c, G[f"upconv{l}.bias"], accumulate=True)
+            ops.conv_wgrad(dprev, dcat, G[f"upconv{l}.weight"], B=B, PH=h, PW=w, QH=hh, QW=ww, R=dcin, Cc=c, KH=2, KW=2,
+                           stride=(2, 2), ldp=dcin, ldq=2 * c, accumulate=True)
+            dd = torch.empty(B * h * w, dcin, device=dev)
+            ops.conv_igemm(dcat, P[f"upconv{l}.weight"], dd, B=B, H=hh, W=ww, Cin=c, OH=h, OW=w, N=dcin, KH=2, KW=2, stride=(2, 2),
+                           ldx=2 * c, ldy=dcin)
+        # bottleneck, then encoder 4..1: skip grad (dcat[:, c:]) + pool backward of the deeper level
+        dpool = block_bwd(self.bott, dd, self.bott.cout)
+        for l in (4, 3, 2, 1):
+            cat, hh, ww, c = ctx["cats"][l]
+            dskip = dcats[l][:, c:]
+            ops.maxpool_bwd(cat[:, c:], 2 * c, dpool, c, dskip, 2 * c, B, hh, ww, c, 2, 2, relu_mask=False, accumulate=True)
+            dpool = block_bwd(self.enc[l - 1], dskip, 2 * c)
+        return None

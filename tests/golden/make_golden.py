@@ -51,13 +51,47 @@ def load_seeded(module, shapes, seed):
     return module
 
 
-def grad_summary(named_params, prefix, out):
+def sample_index(n):
+    """Fixed pseudo-random subset of a flat tensor (same rule in tests/helpers.py)."""
+    if n <= 512:
+        return torch.arange(n)
+    return torch.randperm(n, generator=torch.Generator().manual_seed(1234 + n))[:512]
+
+
+PERTURB = 4e-6   # relative input perturbation of the size of an fp32 forward's accumulated rounding
+
+
+def perturbed(x, seed=99):
+    """x * (1 + PERTURB * N(0,1)): probes how far the exact gradient moves under a change of the size
+    of fp32 rounding in the activations — including ReLU / max-pool decisions that flip."""
+    g = torch.Generator().manual_seed(seed)
+    return x * (1 + PERTURB * torch.randn(x.shape, generator=g, dtype=torch.float64)).to(x.dtype)
+
+
+def grad_summary(named_params, prefix, out, named_params64=None, named_params64p=None):
+    """fp32 reference run: |sum |abs |l2 |head (pins the oracle, same ATen kernels).
+    fp64 reference run (optional): |s64 = fp64 values at sample_index, |l264 = fp64 l2 norm,
+    |dev = l2-relative deviation of the fp32 run from the fp64 run on that sample — the accuracy
+    the reference's own fp32 arithmetic attains on this input, which bounds what an independent
+    fp32 implementation can be asked to match."""
+    p64 = dict(named_params64) if named_params64 is not None else {}
+    p64p = dict(named_params64p) if named_params64p is not None else {}
     for name, p in named_params:
         g = p.grad.detach().double().flatten()
         out[f"{prefix}{name}|sum"] = g.sum().item()
         out[f"{prefix}{name}|abs"] = g.abs().sum().item()
         out[f"{prefix}{name}|l2"] = g.norm().item()
         out[f"{prefix}{name}|head"] = g[:16].numpy().copy()
+        if name in p64:
+            g64 = p64[name].grad.detach().double().flatten()
+            idx = sample_index(g64.numel())
+            out[f"{prefix}{name}|s64"] = g64[idx].numpy().copy()
+            out[f"{prefix}{name}|l264"] = g64.norm().item()
+            out[f"{prefix}{name}|dev"] = ((g[idx] - g64[idx]).norm() / g64[idx].norm().clamp_min(1e-300)).item()
+            if name in p64p:
+                # |cond: movement of the exact (fp64) gradient under the PERTURB-sized input change
+                gp = p64p[name].grad.detach().double().flatten()
+                out[f"{prefix}{name}|cond"] = ((gp[idx] - g64[idx]).norm() / g64[idx].norm().clamp_min(1e-300)).item()
 
 
 def tensor_summary(named, prefix, out):
@@ -66,6 +100,14 @@ def tensor_summary(named, prefix, out):
         out[f"{prefix}{name}|sum"] = v.sum().item()
         out[f"{prefix}{name}|abs"] = v.abs().sum().item()
         out[f"{prefix}{name}|head"] = v[:16].numpy().copy()
+
+
+def dev_of(t32, t64):
+    return ((t32.detach().double() - t64.detach().double()).norm() / t64.detach().double().norm().clamp_min(1e-300)).item()
+
+
+def to64(module):
+    return module.double()
 
 
 def synth_images(b, seed, h=32, w=128):
@@ -96,50 +138,63 @@ def make_unet():
     net = load_seeded(UNet(), mo.unet_state_shapes(), 1).eval()
     with torch.no_grad():
         out["y_eval"] = net(x).numpy()
-    # train-mode forward + backward of scalar*MSE(y, 1) + <y, r>  (Phase B use, :312-329)
-    net = load_seeded(UNet(), mo.unet_state_shapes(), 1).train()
-    y = net(x)
-    r = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+    # train-mode forward + backward of scalar*MSE(y, 1) + <y, r>  (Phase B use, :312-329), fp32 and fp64
+    r = torch.randn(2, 1, 32, 128, generator=torch.Generator().manual_seed(5))
     out["r"] = r.numpy()
-    loss = torch.nn.MSELoss()(y, torch.ones_like(y)) + (y * r).sum() / y.numel()
-    loss.backward()
+    runs = {}
+    for tag, dt in (("32", torch.float32), ("64", torch.float64), ("64p", torch.float64)):
+        net = load_seeded(UNet(), mo.unet_state_shapes(), 1).to(dt).train()
+        y = net(perturbed(x.to(dt)) if tag == "64p" else x.to(dt))
+        loss = torch.nn.MSELoss()(y, torch.ones_like(y)) + (y * r.to(dt)).sum() / y.numel()
+        loss.backward()
+        runs[tag] = (net, y, loss)
+    net, y, loss = runs["32"]
     out["y_train"] = y.detach().numpy()
+    out["y_train64"] = runs["64"][1].detach().numpy()
     out["loss"] = loss.item()
-    grad_summary(net.named_parameters(), "g|", out)
+    out["loss64"] = runs["64"][2].item()
+    grad_summary(net.named_parameters(), "g|", out, runs["64"][0].named_parameters(), runs["64p"][0].named_parameters())
     tensor_summary(((k, v) for k, v in net.state_dict().items() if mo.is_buffer(k)), "buf|", out)
     np.savez_compressed(os.path.join(HERE, "unet_b2.npz"), **out)
-    print("unet_b2", loss.item())
+    print("unet_b2", loss.item(), "max fp32-vs-fp64 grad dev", max(v for k, v in out.items() if k.endswith("|dev")))
 
 
 def make_crnn():
     out = {}
-    x = synth_images(3, 21).requires_grad_()
+    x = synth_images(3, 21)
     labels = synth_labels(3, 3)
     labels[1] = "aa" * 9          # 18 chars with 17 repeats -> needs 35 > 31 frames: infeasible (F3)
     out["labels"] = np.array(labels)
     y, ysz = encode(labels)
     for mode in ("bn_train", "bn_eval"):
-        net = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 2)
-        net.register_backward_hook(net.backward_hook)       # train_nn_patch.py:94
-        net.train()
-        if mode == "bn_eval":                                 # utils.py:113-115 via train_nn_patch.py:314
-            for m in net.modules():
-                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
-                    m.eval()
-        x.grad = None
-        lp = net(x)
-        T = lp.shape[0]
-        insz = torch.tensor([T] * 3, dtype=torch.int)
-        per = torch.nn.CTCLoss(reduction="none")(lp, y, insz, ysz)
-        loss = torch.nn.CTCLoss()(lp, y, insz, ysz)
-        loss.backward()
+        runs = {}
+        for tag, dt in (("32", torch.float32), ("64", torch.float64), ("64p", torch.float64)):
+            net = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 2).to(dt)
+            net.register_backward_hook(net.backward_hook)       # train_nn_patch.py:94
+            net.train()
+            if mode == "bn_eval":                                 # utils.py:113-115 via train_nn_patch.py:314
+                for m in net.modules():
+                    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                        m.eval()
+            xi = (perturbed(x.detach().to(dt)) if tag == "64p" else x.detach().to(dt)).requires_grad_()
+            lp = net(xi)
+            T = lp.shape[0]
+            insz = torch.tensor([T] * 3, dtype=torch.int)
+            per = torch.nn.CTCLoss(reduction="none")(lp, y, insz, ysz)
+            loss = torch.nn.CTCLoss()(lp, y, insz, ysz)
+            loss.backward()
+            runs[tag] = (net, lp, per, loss, xi)
+        net, lp, per, loss, xi = runs["32"]
         out[f"{mode}|lp"] = lp.detach().numpy()
+        out[f"{mode}|lp64"] = runs["64"][1].detach().numpy()
         out[f"{mode}|nll"] = per.detach().numpy()
         out[f"{mode}|loss"] = loss.item()
-        out[f"{mode}|dx"] = x.grad.numpy().copy()
-        grad_summary(net.named_parameters(), f"{mode}|g|", out)
+        out[f"{mode}|dx"] = xi.grad.numpy().copy()
+        out[f"{mode}|dx64"] = runs["64"][4].grad.numpy().copy()
+        grad_summary(net.named_parameters(), f"{mode}|g|", out, runs["64"][0].named_parameters(), runs["64p"][0].named_parameters())
+        out[f"{mode}|dxcond"] = dev_of(runs["64p"][4].grad, runs["64"][4].grad)
         tensor_summary(((k, v) for k, v in net.state_dict().items() if mo.is_buffer(k)), f"{mode}|buf|", out)
-        print("crnn", mode, loss.item(), per.detach().numpy())
+        print("crnn", mode, loss.item(), per.detach().numpy(), "max dev", max(v for k, v in out.items() if k.startswith(mode) and k.endswith("|dev")))
     out["x"] = x.detach().numpy()
     np.savez_compressed(os.path.join(HERE, "crnn_b3.npz"), **out)
 
@@ -300,7 +355,21 @@ def make_step():
         losses.append(loss.item())
     loss.backward()                                      # area trainer: last replica only (F6)
     out["A|losses"] = np.array(losses)
-    grad_summary(crnn.named_parameters(), "A|g|", out)
+    # fp64 twin of the last replica (same noisy input), for the conditioning-aware HIP check
+    crnn64 = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 4).double()
+    crnn64.register_backward_hook(crnn64.backward_hook)
+    crnn64.train()
+    with torch.no_grad():
+        for i in range(inner - 1):                       # earlier replicas only move the BN running stats
+            noisy_i = (preds - torch.from_numpy(out[f"A|noise{i}"])).clamp(0, 1)
+            crnn64(noisy_i.double())
+    lp64 = crnn64(noisy.double())
+    ctc(lp64, y, torch.tensor([lp64.shape[0]] * len(ocr_labels), dtype=torch.int), ysz).backward()
+    crnn64p = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 4).double()
+    crnn64p.register_backward_hook(crnn64p.backward_hook)
+    crnn64p.train()
+    ctc(crnn64p(perturbed(noisy.double())), y, torch.tensor([lp64.shape[0]] * len(ocr_labels), dtype=torch.int), ysz).backward()
+    grad_summary(crnn.named_parameters(), "A|g|", out, crnn64.named_parameters(), crnn64p.named_parameters())
     opt_c.step()
     tensor_summary(crnn.state_dict().items(), "A|crnn|", out)
     # ---- Phase B starts from a freshly seeded CRNN (seed 6), NOT from the post-Phase-A weights:
@@ -322,13 +391,38 @@ def make_step():
     y, ysz = encode(labels)
     lossB = ctc(lp, y, torch.tensor([lp.shape[0]] * B, dtype=torch.int), ysz) + torch.nn.MSELoss()(img, torch.ones_like(img)) * 1.0
     lossB.backward()
-    opt_p.step()
+    prep64 = load_seeded(UNet(), mo.unet_state_shapes(), 3).double().train()
+    crnn64 = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 6).double()
+    crnn64.register_backward_hook(crnn64.backward_hook)
+    crnn64.train()
+    for m in crnn64.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    img64 = prep64(x.double())
+    lp64 = crnn64(img64)
+    loss64 = ctc(lp64, y, torch.tensor([lp64.shape[0]] * B, dtype=torch.int), ysz) + torch.nn.MSELoss()(img64, torch.ones_like(img64)) * 1.0
+    loss64.backward()
+    prep64p = load_seeded(UNet(), mo.unet_state_shapes(), 3).double().train()
+    crnn64p = load_seeded(CRNN(95, False), mo.crnn_state_shapes(), 6).double()
+    crnn64p.register_backward_hook(crnn64p.backward_hook)
+    crnn64p.train()
+    for m in crnn64p.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    img64p = prep64p(perturbed(x.double()))
+    (ctc(crnn64p(img64p), y, torch.tensor([lp64.shape[0]] * B, dtype=torch.int), ysz) + torch.nn.MSELoss()(img64p, torch.ones_like(img64p))).backward()
     out["B|loss"] = lossB.item()
+    out["B|loss64"] = loss64.item()
     out["B|img"] = img.detach().numpy()
+    out["B|img64"] = img64.detach().numpy()
     out["B|lp"] = lp.detach().numpy()
-    grad_summary(prep.named_parameters(), "B|g|prep|", out)
-    grad_summary(crnn.named_parameters(), "B|g|crnn|", out)
+    out["B|lp64"] = lp64.detach().numpy()
+    grad_summary(prep.named_parameters(), "B|g|prep|", out, prep64.named_parameters(), prep64p.named_parameters())
+    grad_summary(crnn.named_parameters(), "B|g|crnn|", out, crnn64.named_parameters(), crnn64p.named_parameters())
+    opt_p.step()
     tensor_summary(prep.state_dict().items(), "B|prep|", out)
+    print("step max dev A", max(v for k, v in out.items() if k.startswith("A|g|") and k.endswith("|dev")),
+          "B", max(v for k, v in out.items() if k.startswith("B|g|") and k.endswith("|dev")))
     out["x"] = x.numpy()
     out["labels"] = np.array(labels)
     out["names"] = np.array(names)

@@ -59,16 +59,84 @@ def check_grad_summary(fix, prefix, named_grads, rtol=2e-4, atol_frac=2e-5, atol
     assert not bad, bad[:6]
 
 
-def check_tensor_summary(fix, prefix, named, rtol=1e-5):
+def check_tensor_summary(fix, prefix, named, rtol=1e-5, atol=0.0):
     bad = []
     for name, t in named:
         v = t.detach().double().flatten().cpu()
         ref_abs = float(fix[f"{prefix}{name}|abs"])
-        if abs(v.abs().sum().item() - ref_abs) > rtol * ref_abs + 1e-9:
+        if abs(v.abs().sum().item() - ref_abs) > rtol * ref_abs + 1e-9 + atol * v.numel():
             bad.append((name, "abs", v.abs().sum().item(), ref_abs))
-        if abs(v.sum().item() - float(fix[f"{prefix}{name}|sum"])) > rtol * ref_abs + 1e-9:
+        if abs(v.sum().item() - float(fix[f"{prefix}{name}|sum"])) > rtol * ref_abs + 1e-9 + atol * v.numel():
             bad.append((name, "sum"))
         head = torch.from_numpy(fix[f"{prefix}{name}|head"])
-        if (v[:head.numel()] - head).abs().max().item() > rtol * max(head.abs().max().item(), 1e-3):
+        if (v[:head.numel()] - head).abs().max().item() > rtol * max(head.abs().max().item(), 1e-3) + atol:
             bad.append((name, "head"))
     assert not bad, bad[:6]
+
+
+def sample_index(n):
+    """Same subset rule as tests/golden/make_golden.py."""
+    if n <= 512:
+        return torch.arange(n)
+    return torch.randperm(n, generator=torch.Generator().manual_seed(1234 + n))[:512]
+
+
+def robust_rel_err(got, ref, frac=0.005):
+    """l2-relative error of `got` against `ref` after discarding the q = max(1, ceil(frac*n)) largest
+    element errors, plus the largest discarded error relative to max|ref|.
+    Why discard: a ReLU / max-pool decision taken on a pre-activation within ~1e-6 of zero can
+    legitimately come out differently in two correct fp32 implementations (measured: ONE such flip
+    among 262 144 activations of the B=2 UNet fixture); it moves a handful of gradient elements by
+    their full magnitude while every other element agrees to ~1e-6.  Per-kernel tests compare every
+    element, so a genuinely wrong region cannot hide behind this allowance."""
+    got = got.detach().double().flatten().cpu()
+    ref = ref.detach().double().flatten().cpu()
+    e = (got - ref).abs()
+    q = max(1, int(-(-frac * e.numel() // 1)))
+    if e.numel() > q:
+        top = e.topk(q)
+        e2 = e.clone()
+        e2[top.indices] = 0
+        worst = top.values[0].item()
+    else:
+        e2, worst = torch.zeros_like(e), e.max().item()
+    den = max(ref.norm().item(), 1e-300)
+    return e2.norm().item() / den, worst / max(ref.abs().max().item(), 1e-300)
+
+
+def check_grad_vs64(fix, prefix, named_grads, rtol=1e-4, k=3.0, atol=2e-7, report=None):
+    """Conditioning-aware gradient check for an independent fp32 implementation.
+
+    The fixture holds, per parameter, the reference's gradient computed in fp64 (|s64, a fixed
+    512-element sample, and |l264) and |dev = the l2-relative deviation of the reference's OWN
+    fp32 run from that fp64 run.  On the small-batch fixtures that deviation reaches 1-2 % for
+    the UNet (batch-statistic BatchNorm over near-constant channels amplifies rounding), so
+    "within 1e-4 of the fp32 CPU numbers" is not a property any independent fp32 path can have
+    there.  |cond is the movement of the reference's fp64 gradient when the input image is perturbed
+    by 4e-6 relative noise (the size of an fp32 forward's accumulated rounding): it also captures
+    ReLU / max-pool decisions that flip, which a single fp32-vs-fp64 sample (|dev) may miss.
+    Required:
+        || hip - ref64 || / || ref64 ||  <=  max(rtol, k * max(dev, cond))
+    i.e. the HIP result is as close to the exact gradient as the reference's own fp32 arithmetic
+    can be expected to be (k = 3 margin), and within rtol = 1e-4 wherever the problem is well
+    conditioned."""
+    bad = []
+    for name, g in named_grads:
+        g = g.detach().double().flatten().cpu()
+        s64 = torch.from_numpy(fix[f"{prefix}{name}|s64"]).double()
+        l264 = float(fix[f"{prefix}{name}|l264"])
+        dev = float(fix[f"{prefix}{name}|dev"])
+        if f"{prefix}{name}|cond" in fix:
+            dev = max(dev, float(fix[f"{prefix}{name}|cond"]))
+        idx = sample_index(g.numel())
+        den = s64.norm().item()
+        floor = atol * idx.numel() ** 0.5
+        tol = max(rtol, k * dev) if den > floor else float("inf")
+        err, worst = robust_rel_err(g[idx], s64)
+        if report is not None:
+            report[name] = (err, dev)
+        if err * den > tol * den + floor:
+            bad.append((name, "sample", err, dev, worst))
+        if abs(g.norm().item() - l264) > (max(rtol, k * dev) if l264 > atol * g.numel() ** 0.5 else 1.0) * l264 + atol * g.numel() ** 0.5:
+            bad.append((name, "l2", g.norm().item(), l264, dev))
+    assert not bad, bad[:8]

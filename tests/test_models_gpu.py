@@ -1,0 +1,220 @@
+"""Whole-network parity of the HIP UNet / CRNN / CTC / Adam path against (a) the golden fixtures
+generated from the reference and (b) the CPU oracle on larger seeded batches."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(module, shapes_fn, seed):
+    from oracle import model_oracle as mo
+    module.load_state_dict(mo.seeded_state(shapes_fn(), seed))
+    return module.cuda()
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def test_unet_golden():
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    fx = H.golden("unet_b2.npz")
+    x = torch.from_numpy(fx["x"]).cuda()
+    net = _load(UNet(), mo.unet_state_shapes, 1).eval()
+    with torch.no_grad():
+        y = net(x)
+    assert np.abs(y.cpu().numpy() - fx["y_eval"]).max() < 2e-5
+    net = _load(UNet(), mo.unet_state_shapes, 1).train()
+    y = net(x)
+    r = torch.from_numpy(fx["r"]).cuda()
+    loss = F.mse_loss(y, torch.ones_like(y)) + (y * r).sum() / y.numel()
+    loss.backward()
+    assert np.abs(y.detach().cpu().numpy() - fx["y_train64"]).max() < 2e-5
+    assert abs(loss.item() - float(fx["loss64"])) < 1e-5
+    H.check_grad_vs64(fx, "g|", ((k, p.grad) for k, p in net.named_parameters()))
+    H.check_tensor_summary(fx, "buf|", ((k, v) for k, v in net.state_dict().items() if mo.is_buffer(k)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["bn_train", "bn_eval"])
+def test_crnn_golden(mode):
+    from models.model_crnn import CRNN
+    from oracle import model_oracle as mo
+    from qea.loss import CTCLoss
+    fx = H.golden("crnn_b3.npz")
+    labels = [str(s) for s in fx["labels"]]
+    y, ysz = H.encode(labels)
+    net = _load(CRNN(95, False), mo.crnn_state_shapes, 2)
+    net.register_backward_hook(net.backward_hook)
+    net.train()
+    if mode == "bn_eval":
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_()
+    lp = net(x)
+    assert lp.shape == (31, 3, 95)
+    assert np.abs(lp.detach().cpu().numpy() - fx[f"{mode}|lp64"]).max() < 2e-4
+    insz = torch.tensor([31] * 3, dtype=torch.int)
+    per = CTCLoss(reduction="none")(lp.detach(), y, insz, ysz).cpu().numpy()
+    ref = fx[f"{mode}|nll"]
+    assert (np.isinf(per) == np.isinf(ref)).all() and np.allclose(per[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=1e-4)
+    loss = CTCLoss()(lp, y, insz, ysz)
+    assert np.isinf(loss.item())
+    loss.backward()
+    dx = x.grad.cpu().numpy()
+    refdx, dx32 = fx[f"{mode}|dx64"], fx[f"{mode}|dx"]
+    assert np.isfinite(dx).all()
+    if mode == "bn_eval":
+        assert np.abs(dx[1]).max() == 0.0
+    dev = max(np.linalg.norm(dx32 - refdx) / np.linalg.norm(refdx), float(fx[f"{mode}|dxcond"]))
+    assert np.linalg.norm(dx - refdx) <= max(1e-4, 3 * dev) * np.linalg.norm(refdx)
+    H.check_grad_vs64(fx, f"{mode}|g|", ((k, p.grad) for k, p in net.named_parameters()))
+    H.check_tensor_summary(fx, f"{mode}|buf|", ((k, v) for k, v in net.state_dict().items() if mo.is_buffer(k)), rtol=1e-4)
+
+
+def _oracle_phase_b(x, labels, su, sc, dtype):
+    from oracle import model_oracle as mo
+    from oracle import step_oracle as so
+    cast = lambda st: {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in st.items()}
+    tr = so.OracleTrainer(cast(su), cast(sc), H.C2I)
+    tr.zero()
+    img = mo.unet_forward(tr.Pu, tr.Bu, x.to(dtype), training=True)
+    lp = mo.crnn_forward(tr.Pc, tr.Bc, img, bn_training=False)
+    y, ysz = H.encode(labels)
+    loss = so.ctc_mean(lp, y, ysz) + F.mse_loss(img, torch.ones_like(img))
+    loss.backward()
+    return tr, img.detach(), lp.detach(), loss.item()
+
+
+@pytest.mark.parametrize("style,B", [("pos", 8), ("uniform", 6)])
+def test_phase_b_vs_oracle(style, B):
+    """UNet(train) -> CRNN(BN eval) -> CTC + MSE -> backward: EVERY gradient tensor against the CPU
+    oracle evaluated in fp64, with the oracle's own fp32 deviation as the conditioning yard-stick."""
+    from models.model_crnn import CRNN
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea.loss import CTCLoss
+    x = H.synth_images(B, 77) if style == "pos" else torch.rand(B, 1, 32, 128, generator=torch.Generator().manual_seed(79))
+    labels = H.synth_labels(B, 78, 1, 10)
+    su, sc = mo.seeded_state(mo.unet_state_shapes(), 11), mo.seeded_state(mo.crnn_state_shapes(), 12)
+    t64, img64, lp64, loss64 = _oracle_phase_b(x, labels, su, sc, torch.float64)
+    t32, img32, _, _ = _oracle_phase_b(x, labels, su, sc, torch.float32)
+    # conditioning probe: exact gradient under a 4e-6 relative input perturbation (see helpers.check_grad_vs64)
+    xp = x * (1 + 4e-6 * torch.randn(x.shape, generator=torch.Generator().manual_seed(99)))
+    t64p, _, _, _ = _oracle_phase_b(xp.double(), labels, su, sc, torch.float64)
+
+    prep = UNet()
+    prep.load_state_dict(su)
+    prep = prep.cuda().train()
+    crnn = CRNN(95, False)
+    crnn.load_state_dict(sc)
+    crnn = crnn.cuda().train()
+    crnn.register_backward_hook(crnn.backward_hook)
+    for m in crnn.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    prep.zero_grad()
+    crnn.zero_grad()
+    img = prep(x.cuda())
+    lp = crnn(img)
+    y, ysz = H.encode(labels)
+    loss = CTCLoss()(lp, y, torch.tensor([31] * B, dtype=torch.int), ysz) + F.mse_loss(img, torch.ones_like(img))
+    loss.backward()
+    assert _rel(img.detach(), img64) < max(1e-5, 3 * _rel(img32, img64))
+    assert (lp.detach().cpu().double() - lp64).abs().max().item() < 2e-4
+    assert abs(loss.item() - loss64) < 1e-4 * abs(loss64)                      # north_star: CTC loss within 1e-4
+    bad = {}
+    for name, p in list(prep.named_parameters()) + list(crnn.named_parameters()):
+        src64 = t64.Pu if name in t64.Pu else t64.Pc
+        src32 = t32.Pu if name in t32.Pu else t32.Pc
+        r64 = src64[name].grad.double()
+        dev = (src32[name].grad.double() - r64).norm().item() / max(r64.norm().item(), 1e-300)
+        srcp = t64p.Pu if name in t64p.Pu else t64p.Pc
+        cond = (srcp[name].grad.double() - r64).norm().item() / max(r64.norm().item(), 1e-300)
+        err, worst = H.robust_rel_err(p.grad, r64)
+        if err > max(1e-4, 3 * max(dev, cond)):
+            bad[name] = (err, dev, cond)
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
+    for name, b in list(prep.named_buffers()):
+        if b.dtype == torch.float32:
+            assert _rel(b, t64.Bu[name]) < 1e-5, name
+
+
+def test_step_golden_with_fused_adam():
+    from models.model_crnn import CRNN
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea.loss import CTCLoss
+    from qea.optim import FusedAdam
+    fx = H.golden("step_area_b4.npz")
+    x = torch.from_numpy(fx["x"]).cuda()
+    labels = [str(s) for s in fx["labels"]]
+    prep = _load(UNet(), mo.unet_state_shapes, 3)
+    crnn = _load(CRNN(95, False), mo.crnn_state_shapes, 4)
+    crnn.register_backward_hook(crnn.backward_hook)
+    opt_c = FusedAdam(crnn.parameters(), lr=1e-4, weight_decay=0)
+    ctc = CTCLoss()
+    # Phase A (train_nn_area.py:212-275) with the fixture's selection, noise and labels
+    crnn.train(); prep.eval(); prep.zero_grad(); crnn.zero_grad()
+    with torch.no_grad():
+        preds_all = prep(x)
+    idx = torch.from_numpy(fx["A|idx"])
+    preds = preds_all[idx.cuda()]
+    losses = []
+    for i in range(2):
+        noisy = (preds - torch.from_numpy(fx[f"A|noise{i}"]).cuda()).clamp(0, 1)
+        lp = crnn(noisy)
+        y, ysz = H.encode([labels[j][::-1] for j in idx.tolist()])
+        loss = ctc(lp, y, torch.tensor([31] * len(idx), dtype=torch.int), ysz)
+        losses.append(loss.item())
+    loss.backward()
+    assert np.allclose(losses, fx["A|losses"], rtol=2e-5)
+    H.check_grad_vs64(fx, "A|g|", ((k, p.grad) for k, p in crnn.named_parameters()))
+    opt_c.step()
+    noise_driven = ("convo.conv5.bias", "convo.conv6.bias")
+    H.check_tensor_summary(fx, "A|crnn|", ((k, v) for k, v in crnn.state_dict().items() if k not in noise_driven), rtol=1e-4)
+    # Phase B from the freshly seeded CRNN of the fixture
+    crnn = _load(CRNN(95, False), mo.crnn_state_shapes, 6)
+    crnn.register_backward_hook(crnn.backward_hook)
+    opt_p = FusedAdam(prep.parameters(), lr=5e-5, weight_decay=0)
+    prep.train(); crnn.train()
+    for m in crnn.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    prep.zero_grad(); crnn.zero_grad()
+    img = prep(x)
+    lp = crnn(img)
+    y, ysz = H.encode(labels)
+    lossB = ctc(lp, y, torch.tensor([31] * 4, dtype=torch.int), ysz) + F.mse_loss(img, torch.ones_like(img)) * 1.0
+    lossB.backward()
+    assert abs(lossB.item() - float(fx["B|loss64"])) < 1e-4 * abs(lossB.item())
+    assert np.abs(img.detach().cpu().numpy() - fx["B|img64"]).max() < 2e-5
+    H.check_grad_vs64(fx, "B|g|prep|", ((k, p.grad) for k, p in prep.named_parameters()))
+    H.check_grad_vs64(fx, "B|g|crnn|", ((k, p.grad) for k, p in crnn.named_parameters()))
+    opt_p.step()
+    # Adam's first step is lr*sign(g): insensitive to the gradient's conditioning except where |g| ~ 0
+    # (a gradient element whose sign is within the conditioning noise moves its weight by up to 2*lr)
+    H.check_tensor_summary(fx, "B|prep|", prep.state_dict().items(), rtol=2e-4, atol=2.1 * 5e-5)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """whole-module pickle (reference checkpoint format) survives save -> load -> forward."""
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    net = _load(UNet(), mo.unet_state_shapes, 1).eval()
+    x = H.synth_images(2, 5).cuda()
+    with torch.no_grad():
+        y0 = net(x)
+    path = tmp_path / "Prep_model_0_12.34"
+    torch.save(net, path)
+    net2 = torch.load(path, weights_only=False).cuda().eval()
+    with torch.no_grad():
+        y1 = net2(x)
+    assert torch.equal(y0, y1)
+    assert list(net2.state_dict().keys()) == list(mo.unet_state_shapes().keys())
