@@ -1,0 +1,215 @@
+"""Headline benchmark: patch-images/sec through one Phase-B pass of the preprocessor-training
+inner loop (BASELINE.json metric) on N MI355X GPUs of one node.
+
+  step = UNet(train BN) -> CRNN(train, BN eval) -> CTC(mean) + MSE(img, 1) -> backward
+         (UNet dgrad+wgrad, CRNN dgrad+wgrad: reference-faithful, 9.846 GFLOP/img) -> [RCCL
+         all-reduce of the flat UNet gradient when N > 1] -> fused Adam(UNet)
+  (reference: train_nn_area.py:277-287 / train_nn_patch.py:312-345)
+
+Inputs are synthetic POS-style 32x128 grey patches already resident in HBM, random-init weights,
+fp32 throughout.  One JSON line on rank 0 (contract in the task statement), plus
+  "roofline":     the implicit-GEMM MFMA conv kernel (dominant), algorithmic flops / HIP-event time
+                  measured over the timed region on the launch stream
+  "cpu_baseline": the CPU oracle (oracle/, a torch-CPU restatement pinned to the reference) timed on
+                  the host cores on a bounded sample — N=1 only.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--full-step]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "query-efficient-approx-to-improve-ocr_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+CHARS = 95
+FLOP_PER_IMG_FAITHFUL = 9.846e9      # 3 x 3.2819 GFLOP (dgrad + wgrad everywhere)
+FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md, fp32-input MFMA (= vector peak)
+
+
+def synth_batch(B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    m = (torch.rand(B, 1, 32, 128, generator=g) < 0.12).float()
+    ink = torch.rand(B, 1, 32, 128, generator=g) * 0.7 + 0.3
+    x = (1 - m * ink + 0.02 * torch.randn(B, 1, 32, 128, generator=g)).clamp(0, 1)
+    lens = torch.randint(1, 13, (B,), generator=g)
+    y = torch.randint(1, CHARS, (int(lens.sum()),), generator=g).to(torch.int32)
+    return x.to(device), y, lens.to(torch.int32)
+
+
+def cpu_baseline(batch=128, steps=8):
+    """Phase-B step of the CPU oracle on the host cores (bounded sample)."""
+    import torch.nn.functional as F
+    from oracle import model_oracle as mo
+    # the GPU box gives a 1-GPU job a 16-core CPU share whatever os.cpu_count() says; oversubscribing
+    # OpenMP far beyond the share makes the CPU leg crawl
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("QEA_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    x, y, lens = synth_batch(batch, 7, "cpu")
+    Pu, Bu = mo.split_state(mo.seeded_state(mo.unet_state_shapes(), 1))
+    Pc, Bc = mo.split_state(mo.seeded_state(mo.crnn_state_shapes(), 2))
+    opt = torch.optim.Adam(list(Pu.values()), lr=5e-5)
+    ins = torch.full((batch,), 31, dtype=torch.int32)
+
+    def step():
+        for p in list(Pu.values()) + list(Pc.values()):
+            p.grad = None
+        img = mo.unet_forward(Pu, Bu, x, training=True)
+        lp = mo.crnn_forward(Pc, Bc, img, bn_training=False)
+        loss = F.ctc_loss(lp, y, ins, lens) + F.mse_loss(img, torch.ones_like(img))
+        loss.backward()
+        opt.step()
+
+    print(f"[bench] cpu_baseline: {cores} threads, B={batch}", file=sys.stderr, flush=True)
+    step()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step()
+        print(f"[bench] cpu_baseline step {i + 1}/{steps} {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
+    dt = time.perf_counter() - t0
+    return {"value": batch * steps / dt, "unit": "patch-images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} Phase-B steps of B={batch} (+1 warm-up), CPU oracle, torch {torch.__version__} CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="patches per GPU (weak scaling)")
+    ap.add_argument("--skip-crnn-wgrad", action="store_true",
+                    help="skip the CRNN weight gradients the reference computes but discards when --update_CRNN is off")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path for the product)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from models.model_crnn import CRNN
+    from models.model_unet import UNet
+    from qea import ops
+    from qea.loss import CTCLoss
+    from qea.optim import FusedAdam
+    from qea.params import ensure_flat
+
+    torch.manual_seed(42)
+    prep = UNet().to(dev)
+    crnn = CRNN(CHARS, False).to(dev)
+    crnn.register_backward_hook(crnn.backward_hook)
+    if args.skip_crnn_wgrad:
+        crnn.__dict__["_qea_skip_param_grads"] = True
+    opt_p = FusedAdam(prep.parameters(), lr=5e-5, weight_decay=0)
+    ctc = CTCLoss()
+    mse = torch.nn.MSELoss()
+    B = args.batch
+    x, y, lens = synth_batch(B, 1000 + rank, dev)
+    ins = torch.full((B,), 31, dtype=torch.int32)
+    ones = torch.ones(B, 1, 32, 128, device=dev)
+    fs = ensure_flat(prep)
+
+    def step():
+        prep.train()
+        crnn.train()
+        for m in crnn.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+        prep.zero_grad()
+        crnn.zero_grad()
+        img = prep(x)
+        lp = crnn(img)
+        loss = ctc(lp, y, ins, lens) + mse(img, ones)
+        loss.backward()
+        if world > 1:
+            dist.all_reduce(fs.grad)
+            fs.grad.mul_(1.0 / world)
+        opt_p.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"[bench] warm-up {i + 1}/{args.warmup} done", file=sys.stderr, flush=True)
+    for k in (ops.PROF_CONV_IGEMM, ops.PROF_CONV_WGRAD, ops.PROF_LSTM_STEP):
+        ops.prof_enable(k, True)
+    ops.prof_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(f"[bench] {args.steps} timed steps in {dt:.3f}s", file=sys.stderr, flush=True)
+    prof = {k: ops.prof_read(k) for k in (ops.PROF_CONV_IGEMM, ops.PROF_CONV_WGRAD, ops.PROF_LSTM_STEP)}
+    for k in prof:
+        ops.prof_enable(k, False)
+
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    if rank == 0:
+        ig, wg, ls = prof[ops.PROF_CONV_IGEMM], prof[ops.PROF_CONV_WGRAD], prof[ops.PROF_LSTM_STEP]
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        out = {
+            "metric": "patch-images/sec UNet->CRNN->CTC fwd+bwd, 32x128 grey",
+            "value": B * world * args.steps / dt,
+            "unit": "patch-images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Phase-B step (UNet train-BN -> CRNN BN-eval -> CTC mean + MSE -> backward -> Adam(UNet)) on "
+                                   "synthetic POS-style 32x128 patches, BASELINE configs[1] batch",
+                       "batch_per_gpu": B, "global_batch": B * world, "crnn_wgrad": not args.skip_crnn_wgrad,
+                       "parallelism": f"dp{world}", "loss": float(loss.item())},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM: conv fwd/dgrad, "
+                                                      "convT, LSTM/linear GEMMs)",
+                         "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "launches_per_step": ig["launches"] / args.steps,
+                         "ms_per_step_in_kernel": ig["ms"] / args.steps},
+            "kernels": {
+                "conv_wgrad": {"tflops": wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0, "ms_per_step": wg["ms"] / args.steps,
+                               "launches_per_step": wg["launches"] / args.steps},
+                "lstm_step": {"tflops": ls["flops"] / (ls["ms"] * 1e-3) / 1e12 if ls["ms"] > 0 else 0.0, "ms_per_step": ls["ms"] / args.steps,
+                              "launches_per_step": ls["launches"] / args.steps},
+            },
+            "end_to_end_tflops": FLOP_PER_IMG_FAITHFUL * B * world * args.steps / dt / 1e12 if not args.skip_crnn_wgrad else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,10 +93,13 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
 }
 
 __global__ void conv_c1_wgrad_finalize_kernel(const float* __restrict__ ws, int nblk, int Co, float* dw, float* db, int accumulate) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // tap*Co + co
+  // one wave per output element: lanes stride over the partial blocks
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // tap*Co + co
   if (e >= 10 * Co) return;
   double s = 0;
-  for (int b = 0; b < nblk; ++b) s += (double)ws[(size_t)b * 10 * Co + e];
+  for (int b = threadIdx.x & 63; b < nblk; b += 64) s += (double)ws[(size_t)b * 10 * Co + e];
+  s = qea_wave_sum_d(s);
+  if ((threadIdx.x & 63) != 0) return;
   const int tap = e / Co, co = e - tap * Co;
   if (tap < 9) {
     float* d = dw + co * 9 + tap;
@@ -206,10 +209,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 __global__ void head_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, int C, float* dw, float* db, int accumulate) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (e > C) return;
   double s = 0;
-  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * (C + 1) + e];
+  for (int b = threadIdx.x & 63; b < nblk; b += 64) s += ws[(size_t)b * (C + 1) + e];
+  s = qea_wave_sum_d(s);
+  if ((threadIdx.x & 63) != 0) return;
   float* d = (e < C) ? dw + e : db;
   *d = accumulate ? *d + (float)s : (float)s;
 }
@@ -262,7 +267,7 @@ extern "C" int qea_conv_c1_wgrad(const float* x, const float* dy, int32_t lddy, 
   }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(grid), dim3(256), lds, s, x, dy, lddy, B, H, W, Co, rt, (float*)workspace);
-  hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(qea_cdiv(10 * Co, 128)), dim3(128), 0, s, (const float*)workspace, grid, Co, dw, db,
+  hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(qea_cdiv(10 * Co, 4)), dim3(256), 0, s, (const float*)workspace, grid, Co, dw, db,
                      accumulate);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
@@ -314,7 +319,7 @@ extern "C" int qea_head_bwd(const float* x, int32_t ldx, const float* y, const f
     case 64: hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, ldx, y, dyy, w, dx, lddx, (long long)M, (double*)workspace); break;
     default: qea_set_error("qea_head_bwd: C=%d not in {32,64}", C); return QEA_ERR_INVALID;
   }
-  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(1), dim3(128), 0, s, (const double*)workspace, grid, C, dw, db, accumulate);
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(qea_cdiv(C + 1, 4)), dim3(256), 0, s, (const double*)workspace, grid, C, dw, db, accumulate);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

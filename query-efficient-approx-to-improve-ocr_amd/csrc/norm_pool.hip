@@ -25,7 +25,7 @@ ColGeom col_geom(long long M, int C) {
   g.rt = RED_THREADS / g.cols;
   if (g.rt < 1) g.rt = 1;
   long long want = (M + (long long)g.rt * 16 - 1) / ((long long)g.rt * 16);
-  if (want > 1024) want = 1024;
+  if (want > 512) want = 512;
   if (want < 1) want = 1;
   g.grid = (int)want;
   g.rows_per_block = (int)((M + g.grid - 1) / g.grid);
@@ -104,17 +104,28 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __r
   }
 }
 
+// Finalize kernels: ONE WAVE PER CHANNEL.  Lane l sums partial blocks l, l+64, ... then a wave
+// reduction; a single thread walking up to 1024 dependent L2 loads per channel took ~200 us.
+__device__ __forceinline__ void partial_sums(const double* __restrict__ ws, int nblk, int C, int c, double& s, double& q) {
+  const int lane = threadIdx.x & 63;
+  double a = 0, b = 0;
+  for (int k = lane; k < nblk; k += 64) {
+    a += ws[((size_t)k * C + c) * 2 + 0];
+    b += ws[((size_t)k * C + c) * 2 + 1];
+  }
+  s = qea_wave_sum_d(a);
+  q = qea_wave_sum_d(b);
+}
+
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ ws, int nblk, int C, long long M, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, float eps, float momentum, float* running_mean,
                                          float* running_var, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                                          double* stat64) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s = 0, q = 0;
-  for (int b = 0; b < nblk; ++b) {
-    s += ws[((size_t)b * C + c) * 2 + 0];
-    q += ws[((size_t)b * C + c) * 2 + 1];
-  }
+  double s, q;
+  partial_sums(ws, nblk, C, c, s, q);
+  if ((threadIdx.x & 63) != 0) return;
   const double mean = s / (double)M;
   double var = q / (double)M - mean * mean;  // biased (normalisation)
   if (var < 0) var = 0;
@@ -151,23 +162,22 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
 }
 
 __global__ void colsum_finalize_kernel(const double* __restrict__ ws, int nblk, int C, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s = 0;
-  for (int b = 0; b < nblk; ++b) s += ws[((size_t)b * C + c) * 2 + 0];
+  double s, q;
+  partial_sums(ws, nblk, C, c, s, q);
+  if ((threadIdx.x & 63) != 0) return;
   out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, int C, long long M, const float* __restrict__ gamma,
                                        const float* __restrict__ invstd, const double* __restrict__ stat64, int training, float* dgamma,
                                        float* dbeta, int accumulate, double* k0, double* k1, double* k2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s = 0, q = 0;
-  for (int b = 0; b < nblk; ++b) {
-    s += ws[((size_t)b * C + c) * 2 + 0];
-    q += ws[((size_t)b * C + c) * 2 + 1];
-  }
+  double s, q;
+  partial_sums(ws, nblk, C, c, s, q);
+  if ((threadIdx.x & 63) != 0) return;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
   const float g = gamma ? gamma[c] : 1.f;
@@ -358,7 +368,7 @@ extern "C" int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
   hipLaunchKernelGGL(colreduce_kernel<0>, dim3(g.grid), dim3(RED_THREADS), lds, s, y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr,
                      nullptr, (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, g.grid, C,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, (const double*)workspace, g.grid, C,
                      (long long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out,
                      stat64);
   QEA_CHECK_LAUNCH();
@@ -402,7 +412,7 @@ extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
   hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.grid), dim3(RED_THREADS), lds, s, da, ldda, a, lda, y, ldy, mean, invstd, stat64,
                      (long long)M, C, g.rows_per_block, g.rt, ws);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)ws, g.grid, C, (long long)M, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, (const double*)ws, g.grid, C, (long long)M, gamma,
                      invstd, stat64, training, dgamma, dbeta, accumulate_param_grads, k0, k1, k2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, s, da, ldda, a, lda, y, ldy, dy, lddy, (long long)M, C,
                      mean, invstd, stat64, (const double*)k0, (const double*)k1, (const double*)k2);
@@ -421,7 +431,7 @@ extern "C" int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, flo
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
   hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.grid), dim3(RED_THREADS), lds, s, x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
                      nullptr, (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(qea_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, g.grid, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, (const double*)workspace, g.grid, C, out, accumulate);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
