@@ -1,0 +1,81 @@
+"""Data parallelism: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo"
+for the CPU rehearsal in tests).  The minibatch is sharded along N, BatchNorm statistics stay local
+(no SyncBN), and each optimiser step exchanges ONE flat fp32 gradient buffer:
+CRNN grads (35.0 MB) after Phase A, UNet grads (31.1 MB) after Phase B — two all-reduces per step,
+because the CRNN update sits between the phases."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(device=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run); no-op for 1 process."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or (dist.is_available() and dist.is_initialized()):
+        return world()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if device is not None and device.type == "cuda":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group("gloo")
+    return world()
+
+
+def allreduce_mean_(flat):
+    """In-place average of one flat gradient buffer over the ranks (sum all-reduce, then 1/world)."""
+    w = world()
+    if w > 1:
+        dist.all_reduce(flat)
+        flat.mul_(1.0 / w)
+    return flat
+
+
+def allreduce_module_grads(module):
+    """Average a module's gradients: one collective on the flat buffer when the module is flat
+    (qea/params.py), else one per parameter."""
+    if world() == 1:
+        return
+    fs = module.__dict__.get("_qea_flat_state")
+    if fs is not None and fs.intact():
+        fs.attach_grads()
+        allreduce_mean_(fs.grad)
+        return
+    for p in module.parameters():
+        if p.grad is not None:
+            allreduce_mean_(p.grad)
+
+
+def global_topk(local_cers, k_global):
+    """TopKCER over the WHOLE minibatch when it is sharded: all-gather the per-shard CERs,
+    rank them in the global stable-descending order (rank-major index as the tie-break), and return
+    (local indices of the winners that live in this shard, k_global).  The caller weights its loss
+    by len(local)/k_global so that averaged gradients equal the global-batch mean."""
+    w, r = world(), rank()
+    vals = torch.as_tensor(local_cers, dtype=torch.float32)
+    if w == 1:
+        order = torch.argsort(-vals, stable=True)[:k_global]
+        return order, k_global
+    n_local = torch.tensor([vals.numel()], dtype=torch.int64)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(w)]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    sizes = [s.to(dev) for s in sizes]
+    dist.all_gather(sizes, n_local.to(dev))
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    padded = torch.full((mx,), float("-inf"), device=dev)
+    padded[:vals.numel()] = vals.to(dev)
+    gathered = [torch.empty(mx, device=dev) for _ in range(w)]
+    dist.all_gather(gathered, padded)
+    allv = torch.cat([g[:s].cpu() for g, s in zip(gathered, sizes)])
+    order = torch.argsort(-allv, stable=True)[:k_global]
+    start = sum(sizes[:r])
+    mine = order[(order >= start) & (order < start + sizes[r])] - start
+    return mine, k_global

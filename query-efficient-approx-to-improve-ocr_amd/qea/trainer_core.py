@@ -1,0 +1,218 @@
+"""Shared machinery of the two preprocessor trainers (train_nn_area.py / train_nn_patch.py).
+
+What the reference keeps in two near-identical 400-line scripts — model/optimiser set-up, the
+`_call_model` / `_get_loss` helpers, validation, checkpoints and experiment-directory files — lives
+here once; the two trainer classes add only their data flow and Phase-A/Phase-B loops.
+
+`Backend` is the seam between host logic and arithmetic: the default one is the HIP path
+(models.*, qea.loss.CTCLoss, qea.optim.FusedAdam on cuda:LOCAL_RANK) and has NO CPU variant; tests
+inject a backend built on the CPU oracle to exercise the host logic without a GPU.
+"""
+import json
+import math
+import os
+import shutil
+
+import torch
+
+import properties
+from qea import dist as qdist
+from utils import (compare_labels, create_dirs, get_char_maps, get_ocr_helper, pred_to_string, save_all_jsons, save_img,
+                   set_bn_eval, set_random_seeds)
+
+
+class Backend:
+    def __init__(self, unet_cls, crnn_cls, ctc_cls, adam_cls, device, gpu_jitter):
+        self.UNet, self.CRNN, self.CTCLoss, self.Adam = unet_cls, crnn_cls, ctc_cls, adam_cls
+        self.device, self.gpu_jitter = device, gpu_jitter
+
+
+def hip_backend():
+    if not torch.cuda.is_available():
+        raise RuntimeError("the product trainers run on the MI355X HIP path only (torch.cuda is not available); "
+                           "there is no CPU implementation — tests inject the CPU oracle explicitly")
+    from models.model_crnn import CRNN
+    from models.model_unet import UNet
+    from qea import _lib
+    from qea.loss import CTCLoss
+    from qea.optim import FusedAdam
+    _lib.lib()                                                   # fail now, loudly, if libqea_hip.so is missing
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    return Backend(UNet, CRNN, CTCLoss, FusedAdam, torch.device("cuda", local), gpu_jitter=True)
+
+
+class _NullLogger:
+    """wandb is optional (reference default: mode 'disabled', wandb_config.json:1-5)."""
+
+    def log(self, *_a, **_k):
+        pass
+
+    def save(self, *_a, **_k):
+        pass
+
+    def summary_update(self, *_a, **_k):
+        pass
+
+
+def _logger():
+    try:
+        import wandb
+        if wandb.run is None:
+            return _NullLogger()
+
+        class _W(_NullLogger):
+            def log(self, d):
+                wandb.log(d)
+
+            def save(self, p):
+                wandb.save(p)
+
+            def summary_update(self, d):
+                wandb.run.summary.update(d)
+        return _W()
+    except ImportError:
+        return _NullLogger()
+
+
+class TrainerCore:
+    """Everything the two TrainNNPrep classes share.  Attribute names follow the reference's."""
+
+    def _setup_common(self, args, backend, ocr, weight_decay):
+        self.backend = backend or hip_backend()
+        self.device = self.backend.device
+        self.lr_crnn, self.lr_prep = args.lr_crnn, args.lr_prep
+        self.max_epochs, self.warmup_epochs = args.epoch, args.warmup_epochs
+        self.inner_limit, self.inner_limit_skip = args.inner_limit, args.inner_limit_skip
+        self.sec_loss_scalar, self.ocr_name = args.scalar, args.ocr
+        self.std, self.is_random_std = args.std, args.random_std
+        self.start_epoch = args.start_epoch
+        self.selection_method = args.minibatch_subset
+        self.train_subset_size, self.val_subset_size = args.train_subset_size, args.val_subset_size
+        self.window_size, self.weightgen_method = args.window_size, args.weightgen_method
+        create_dirs(self, args)
+        set_random_seeds(args.random_seed)
+        self.world = qdist.init_from_env(self.device)
+        self.rank = qdist.rank()
+        self.log = _logger()
+
+        self.train_batch_prop = 1
+        if args.minibatch_subset_prop is not None and self.selection_method:
+            self.train_batch_prop = args.minibatch_subset_prop
+        self.cers, self.selected_samples = None, dict()
+        if args.cers_ocr_path:
+            with open(args.cers_ocr_path, "r") as f:
+                self.cers = json.load(f)
+            self.selected_samples = {k: [False] * self.max_epochs for k in self.cers}
+        self.tracked_labels = {name: [] for name in self.cers} if self.cers else {}
+
+        self.char_to_index, self.index_to_char, self.vocab_size = get_char_maps(properties.char_set)
+        self.input_size = properties.input_size
+        self.ocr = ocr if ocr is not None else get_ocr_helper(self.ocr_name)
+
+        B = self.backend
+        self.crnn_model = (B.CRNN(self.vocab_size, False) if self.crnn_model_path is None
+                           else torch.load(self.crnn_model_path, weights_only=False)).to(self.device)
+        self.crnn_model.register_backward_hook(self.crnn_model.backward_hook)
+        self.prep_model = (B.UNet() if self.prep_model_path is None
+                           else torch.load(self.prep_model_path, weights_only=False)).to(self.device)
+        if self.world > 1:                                       # identical start on every rank
+            for m in (self.crnn_model, self.prep_model):
+                for t in list(m.parameters()) + list(m.buffers()):
+                    torch.distributed.broadcast(t.data, 0)
+
+        from label_tracking import tracking_methods
+        self.loss_wghts_gnrtr = tracking_methods.weightgenerator_factory(args.weightgen_method)(args, self.device, self.char_to_index)
+        self.primary_loss_fn = B.CTCLoss().to(self.device)
+        self.primary_loss_fn_sample_wise = B.CTCLoss(reduction="none").to(self.device)
+        self.secondary_loss_fn = torch.nn.MSELoss().to(self.device)
+        self.optimizer_crnn = B.Adam(self.crnn_model.parameters(), lr=self.lr_crnn, weight_decay=weight_decay)
+        self.optimizer_prep = B.Adam(self.prep_model.parameters(), lr=self.lr_prep, weight_decay=weight_decay)
+
+    def _make_sampler(self, needs_cers):
+        from selection_utils import datasampler_factory
+        if not self.selection_method:
+            self.sampler = None
+            return
+        cls = datasampler_factory(self.selection_method)
+        self.sampler = cls(self.cers) if needs_cers else cls()
+
+    # ---- reference helpers (train_nn_patch.py:158-191) ----
+    def _call_model(self, images, labels):
+        scores = self.crnn_model(images.to(self.device))
+        out_size = torch.tensor([scores.shape[0]] * images.shape[0], dtype=torch.int)
+        y_size = torch.tensor([len(l) for l in labels], dtype=torch.int)
+        y = torch.tensor([self.char_to_index[c] for c in "".join(labels)], dtype=torch.int)
+        return scores, y, out_size, y_size
+
+    def _get_loss(self, scores, y, pred_size, y_size, img_preds):
+        pri = self.primary_loss_fn(scores, y, pred_size, y_size)
+        sec = self.secondary_loss_fn(img_preds, torch.ones(img_preds.shape, device=img_preds.device)) * self.sec_loss_scalar
+        return pri + sec
+
+    def _jitter(self, imgs, noiser):
+        """One jittered copy of every image.  HIP: one Philox kernel for the whole stack (images stay in
+        HBM); injected CPU backend: the reference's per-image loop (train_nn_patch.py:187-191)."""
+        if self.backend.gpu_jitter and imgs.is_cuda:
+            out, _ = noiser.batch(imgs, replicas=1)
+            return out
+        res = [noiser(img) for img in imgs]
+        return torch.stack([r[0] if isinstance(r, tuple) else r for r in res])
+
+    def _num_bb_samples(self, n):
+        return max(1, math.ceil(n * (1 - self.train_batch_prop)))
+
+    def _set_phase_a(self):
+        self.crnn_model.train()
+        self.prep_model.eval()
+        self.prep_model.zero_grad()
+        self.crnn_model.zero_grad()
+
+    def _set_phase_b(self):
+        self.prep_model.train()
+        self.crnn_model.train()
+        self.crnn_model.apply(set_bn_eval)
+        self.prep_model.zero_grad()
+        self.crnn_model.zero_grad()
+
+    def _step_crnn(self):
+        qdist.allreduce_module_grads(self.crnn_model)
+        self.optimizer_crnn.step()
+
+    def _step_prep(self, also_crnn=False):
+        qdist.allreduce_module_grads(self.prep_model)
+        if also_crnn:
+            qdist.allreduce_module_grads(self.crnn_model)
+            self.optimizer_crnn.step()
+        self.optimizer_prep.step()
+
+    # ---- epoch end: checkpoints in the reference layout (train_nn_patch.py:440-464) ----
+    def _save_checkpoints(self, epoch, ocr_accuracy, best, save_optim):
+        if self.rank != 0:
+            return best
+        prep_ckpt = os.path.join(self.ckpt_base_path, f"Prep_model_{epoch}_{ocr_accuracy * 100:.2f}")
+        torch.save(self.prep_model, prep_ckpt)
+        torch.save(self.crnn_model, os.path.join(self.ckpt_base_path, "CRNN_model_" + str(epoch)))
+        if save_optim:
+            torch.save(self.optimizer_prep.state_dict(), os.path.join(self.ckpt_base_path, "optim_prep_latest"))
+            torch.save(self.optimizer_crnn.state_dict(), os.path.join(self.ckpt_base_path, "optim_crnn_latest"))
+        best_acc, best_epoch = best
+        if ocr_accuracy > best_acc:
+            best_acc, best_epoch = ocr_accuracy, epoch
+            best_path = os.path.join(self.ckpt_base_path, "Prep_model_best")
+            shutil.copyfile(prep_ckpt, best_path)
+            self.log.save(best_path)
+            self.log.summary_update({"best_val_acc": best_acc, "best_val_epoch": best_epoch})
+        return best_acc, best_epoch
+
+    def _epoch_jsons(self, epoch):
+        if self.selection_method and self.rank == 0:
+            save_all_jsons(self, epoch)
+
+    def _update_cers(self, scores, labels, names):
+        """decode -> per-sample CER -> sampler.update_cer (train_nn_patch.py:330-342)."""
+        model_gen_labels = pred_to_string(scores, labels, self.index_to_char)
+        if self.selection_method and len(names):
+            batch_cers = [compare_labels([p], [l])[1] for p, l in zip(model_gen_labels, labels)]
+            self.sampler.update_cer(batch_cers, names)
+        return model_gen_labels

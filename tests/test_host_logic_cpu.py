@@ -1,0 +1,123 @@
+"""Host-side mirror of the reference interface (samplers, helpers, CLI flags, constants) on CPU."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import helpers as H
+
+
+def test_properties_constants():
+    import properties
+    assert properties.char_set == H.CHAR_SET and properties.char_set[0] == "`"
+    assert properties.input_size == (32, 128) and properties.max_char_len == 100 and properties.empty_char == " "
+    assert properties.prep_crnn_ckpts == "ckpts" and properties.img_out == "img_out" and properties.param_path == "params.txt"
+    assert properties.patch_dataset_train == "patch_dataset_train" and properties.vgg_text_dataset_dev == "vgg_dev"
+
+
+def test_topk_sampler_matches_reference_cases(golden_dir):
+    from selection_utils import datasampler_factory
+    cases = json.load(open(os.path.join(golden_dir, "topk_cases.json")))["cases"]
+    for c in cases:
+        s = datasampler_factory("topKCER")(dict(c["cers"]))
+        imgs = torch.arange(len(c["names"])).float().view(-1, 1)
+        sel, labels, idx = s.query(imgs, list(c["names"]), c["k"], list(c["names"]))
+        vals = np.float32([c["cers"][n] for n in c["names"] if n in c["cers"]])
+        if "build-specific" in c["note"] or "real slice" in c["note"]:
+            assert sorted(vals[idx].tolist()) == sorted(vals[c["idx"]].tolist())
+        else:
+            assert idx.tolist() == c["idx"], c["note"]
+            if c["sel"] is not None:
+                assert sel.view(-1).long().tolist() == c["sel"]
+        assert labels == [c["names"][i] for i in idx.tolist()]
+
+
+def test_sampler_protocol_and_factory_keys():
+    from selection_utils import datasampler_factory
+    for key in ("random", "topKCER", "uniformCERglobal", "randomglobal", "rangeCER", "uniformEntropy"):
+        assert datasampler_factory(key)
+    s = datasampler_factory("topKCER")({"a": 0.1})
+    s.update_cer([0.5, 0.25], ["a", "b"])
+    assert s.cers == {"a": 0.5, "b": 0.25} and s.all_cers == {"a": [0.5], "b": [0.25]}
+    imgs = torch.arange(6).float().view(-1, 1)
+    r = datasampler_factory("random")()
+    sel, lab, idx = r.query(imgs, list("abcdef"), 3)
+    assert sel.shape[0] == 3 and len(set(idx.tolist())) == 3
+    rg = datasampler_factory("rangeCER")({n: i / 10 for i, n in enumerate("abcdef")})
+    sel, lab, idx = rg.query(imgs, list("abcdef"), 2, list("abcdef"))
+    assert len(set(idx.tolist())) == 2
+    g = datasampler_factory("uniformCERglobal")({n: i / 10 for i, n in enumerate("abcdef")}, 2)
+    g.select_samples()
+    sel, lab, idx = g.query(imgs, list("abcdef"), names=list("abcdef"))
+    assert len(idx) == 2
+
+
+def test_utils_helpers_match_reference_fixtures(tmp_path):
+    import utils
+    fx = H.golden("helpers.npz")
+    c2i, i2c, n = utils.get_char_maps(H.CHAR_SET)
+    assert n == 95 and c2i["`"] == 0 and i2c[94] == "/"
+    assert utils.pred_to_string(torch.from_numpy(fx["dec|scores"]), [""] * 6, i2c) == [str(s) for s in fx["dec|strings"]]
+    boxes = [dict(label=str(i), x_min=int(b[0]), y_min=int(b[1]), x_max=int(b[2]), y_max=int(b[3])) for i, b in enumerate(fx["crop|boxes"])]
+    stack, labels = utils.get_text_stack(torch.from_numpy(fx["crop|page"]), boxes, (32, 128))
+    assert np.array_equal(stack.numpy(), fx["crop|stack"]) and labels == ["0", "1", "2", "3"]
+    assert utils.compare_labels(["kitten", "abc"], ["sitting", "abc"]) == (1, 3 / 7)
+    bn = torch.nn.BatchNorm2d(3).train()
+    utils.set_bn_eval(bn)
+    assert not bn.training
+
+    class T:
+        pass
+    t, args = T(), type("A", (), dict(crnn_model=None, prep_model=None, data_base_path=".", exp_base_path=str(tmp_path / "exp")))()
+    utils.create_dirs(t, args)
+    for d in ("ckpts", "img_out", "cers", "tracked_labels", "selected_samples"):
+        assert os.path.isdir(tmp_path / "exp" / d)
+    utils.save_img(torch.rand(3, 1, 8, 16), "grid", str(tmp_path), 2)
+    assert os.path.exists(tmp_path / "grid.png")
+
+
+def test_add_gaussian_noice_call_semantics():
+    from oracle import path_oracle as po
+    from transform_helper import AddGaussianNoice
+    fx = H.golden("helpers.npz")
+    img = torch.from_numpy(fx["jit|img"])
+    for stochastic, tag in ((False, "jit0"), (True, "jit1")):
+        torch.manual_seed(123)
+        out, noise = AddGaussianNoice(std=5, is_stochastic=stochastic, return_noise=True)(img.clone())
+        assert np.array_equal(noise.numpy(), fx[f"{tag}|noise"]) and np.array_equal(out.numpy(), fx[f"{tag}|out"])
+    torch.manual_seed(123)
+    out = AddGaussianNoice(std=3)(img.clone(), noise_coef=0.5)
+    assert np.array_equal(out.numpy(), po.jitter(img.numpy(), fx["jitc|noise"], 0.5))
+
+
+def test_tracking_utils_and_stub_ocr():
+    import tracking_utils as tu
+    from label_tracking.tracking_methods import weightgenerator_factory
+    from ocr_helper.stub_helper import StubHelper
+
+    class T:
+        window_size, weightgen_method, char_to_index = 3, "decaying", H.C2I
+        tracked_labels = {"a": ["x", "yy"], "b": ["z"], "c": []}
+    t = T()
+    tu.add_labels_to_history(t, ["a", "c"], ["new", "cc"])
+    assert t.tracked_labels["a"][-1] == "new" and t.tracked_labels["c"] == ["cc"]
+    batches = tu.generate_ctc_target_batches(t, ["a", "b", "c"])
+    assert [b[2] for b in batches] == [[0, 1, 2], [0], [0]]
+    assert batches[0][1].tolist() == [3, 1, 2]
+    args = type("A", (), dict(decay_factor=0.5, window_size=3))()
+    w = weightgenerator_factory("decaying")(args, "cpu").gen_weights(None, None)
+    assert w.tolist() == [1.0, 0.5, 0.25]
+    ocr = StubHelper()
+    imgs = H.synth_images(5, 3)
+    a, b = ocr.get_labels(imgs), ocr.get_labels(imgs)
+    assert a == b and ocr.count_calls == 10 and all(set(l) <= set(H.CHAR_SET) and 0 < len(l) <= 100 for l in a)
+
+
+def test_cli_flag_surface():
+    from qea.cli_flags import build_parser
+    p = build_parser("p", "").parse_args([])
+    assert (p.lr_crnn, p.lr_prep, p.epoch, p.std, p.inner_limit, p.weight_decay, p.minibatch_subset_prop) == (1e-4, 5e-5, 25, 5, 2, 5e-4, 0.5)
+    assert p.random_std is True and p.ocr == "Tesseract" and p.weightgen_method == "decaying" and p.decay_factor == 0.7
+    a = build_parser("a", "").parse_args(["--minibatch_subset", "topKCER", "--random_std", "--lr_scheduler", "cosine"])
+    assert a.batch_size == 32 and a.epoch == 50 and a.random_std is False and not hasattr(a, "weight_decay")

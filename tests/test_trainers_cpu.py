@@ -1,0 +1,136 @@
+"""Plumbing of the two trainers on CPU (BASELINE configs[0]): the product's host logic (flags ->
+TrainNNPrep -> Phase A/B loop -> experiment files and whole-module checkpoints) driven with the CPU
+oracle INJECTED as the arithmetic backend, the stub OCR and synthetic data; plus the data-parallel
+path with gloo at world_size 2 against its single-process specification."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H
+
+torch.set_num_threads(4)
+
+
+def oracle_backend():
+    from oracle.modules import OracleCRNN, OracleUNet
+    from qea.trainer_core import Backend
+    return Backend(OracleUNet, OracleCRNN, torch.nn.CTCLoss, torch.optim.Adam, torch.device("cpu"), gpu_jitter=False)
+
+
+def _args(which, tmp, **over):
+    from qea.cli_flags import build_parser
+    a = build_parser(which, "").parse_args(["--exp_base_path", str(tmp), "--ocr", "stub", "--epoch", "1", "--inner_limit", "1"])
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_area_trainer_plumbing(tmp_path):
+    from datasets.synthetic import SyntheticTextAreas
+    from ocr_helper.stub_helper import StubHelper
+    from train_nn_area import TrainNNPrep
+    tr_set = SyntheticTextAreas(8, seed=1, include_name=True, include_index=True)
+    cers = {n: float(i % 3) / 2 for i, n in enumerate(tr_set.names)}
+    cers_path = tmp_path / "cers.json"
+    json.dump(cers, open(cers_path, "w"))
+    args = _args("a", tmp_path / "exp", batch_size=4, minibatch_subset="topKCER", minibatch_subset_prop=0.5, cers_ocr_path=str(cers_path),
+                 inner_limit=2, inner_limit_skip=True, window_size=2)
+    ocr = StubHelper()
+    t = TrainNNPrep(args, backend=oracle_backend(), train_set=tr_set, val_set=SyntheticTextAreas(4, seed=2, include_name=True), ocr=ocr)
+    w0 = [p.detach().clone() for p in t.prep_model.parameters()]
+    c0 = [p.detach().clone() for p in t.crnn_model.parameters()]
+    best = t.train()
+    assert isinstance(best, tuple) and len(best) == 2
+    assert any((a != b).any() for a, b in zip(w0, t.prep_model.parameters()))        # Phase B stepped the UNet
+    assert any((a != b).any() for a, b in zip(c0, t.crnn_model.parameters()))        # Phase A stepped the CRNN
+    # 2 minibatches x k=2 strips x 2 inner iterations (+ validation: 4) black-box calls
+    assert ocr.count_calls == 2 * 2 * 2 + 4
+    exp = tmp_path / "exp"
+    assert os.path.exists(exp / "ckpts" / "CRNN_model_0") and any(f.startswith("Prep_model_0_") for f in os.listdir(exp / "ckpts"))
+    assert json.load(open(exp / "cers" / "all_cers.json")).keys() == cers.keys()
+    tracked = json.load(open(exp / "tracked_labels" / "tracked_labels_current.json"))
+    assert sum(len(v) for v in tracked.values()) == 4                                # one history entry per selected strip
+    sel = json.load(open(exp / "selected_samples" / "selected_samples_current.json"))
+    assert sum(v[0] for v in sel.values()) == 4
+    assert os.path.exists(exp / "img_out" / "out_0.png")
+    # the sampler's CERs were refreshed from the CRNN's greedy decodes
+    assert set(t.sampler.all_cers.keys()) == set(tr_set.names)
+    crnn = torch.load(exp / "ckpts" / "CRNN_model_0", weights_only=False)
+    assert list(crnn.state_dict().keys())
+
+
+def test_patch_trainer_plumbing(tmp_path):
+    from datasets.synthetic import SyntheticPatches
+    from ocr_helper.stub_helper import StubHelper
+    from train_nn_patch import TrainNNPrep
+    tr_set = SyntheticPatches(2, seed=1, strips=(2, 3), pad_shape=(80, 256))
+    names = []
+    for i in range(len(tr_set)):
+        _, boxes, name = tr_set[i]
+        names += TrainNNPrep._strip_names([b["label"] for b in boxes], name)
+    cers_path = tmp_path / "cers.json"
+    json.dump({n: 0.5 for n in names}, open(cers_path, "w"))
+    args = _args("p", tmp_path / "exp", minibatch_subset="topKCER", minibatch_subset_prop=0.5, cers_ocr_path=str(cers_path), inner_limit=2,
+                 update_CRNN=True)
+    ocr = StubHelper()
+    t = TrainNNPrep(args, backend=oracle_backend(), train_set=tr_set, val_set=SyntheticPatches(1, seed=2, strips=(2, 2), pad_shape=(80, 256),
+                                                                                             include_name=False), ocr=ocr)
+    t.train()
+    exp = tmp_path / "exp"
+    for f in ("CRNN_model_0", "optim_prep_latest", "optim_crnn_latest"):
+        assert os.path.exists(exp / "ckpts" / f), f
+    st = torch.load(exp / "ckpts" / "optim_prep_latest", weights_only=False)
+    assert set(st.keys()) == {"state", "param_groups"} and st["param_groups"][0]["weight_decay"] == 5e-4
+    assert set(json.load(open(exp / "cers" / "all_cers.json")).keys()) == set(names)
+    assert ocr.count_calls > 0
+
+
+# ----------------------------------------------------------------------------- data parallel (gloo, 2 ranks)
+def _dp_worker(rank, world, port, tmp, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "query-efficient-approx-to-improve-ocr_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    from datasets.synthetic import SyntheticTextAreas
+    from ocr_helper.stub_helper import StubHelper
+    from qea import dist as qdist
+    from train_nn_area import TrainNNPrep
+    args = _args("a", os.path.join(tmp, f"exp{rank}"), batch_size=2, inner_limit=1)
+    t = TrainNNPrep(args, backend=oracle_backend(), train_set=SyntheticTextAreas(4, seed=1, include_name=True, include_index=True),
+                    val_set=SyntheticTextAreas(2, seed=2, include_name=True), ocr=StubHelper())
+    assert t.world == world
+    # gradient exchange == mean of the shard gradients (checked by the parent): one Phase-B backward on a rank-specific shard
+    x = H.synth_images(2, 100 + rank)
+    t._set_phase_b()
+    img = t.prep_model(x)
+    scores, y, ps, ys = t._call_model(img, H.synth_labels(2, 200 + rank, 2, 6))
+    t._get_loss(scores, y, ps, ys, img).backward()
+    local = torch.cat([p.grad.flatten().clone() for p in t.prep_model.parameters()])
+    qdist.allreduce_module_grads(t.prep_model)
+    reduced = torch.cat([p.grad.flatten().clone() for p in t.prep_model.parameters()])
+    t.train()
+    mine, k = qdist.global_topk([0.1 * (rank + 1), 0.9 - 0.5 * rank, 0.3], 3)
+    flat = torch.cat([p.detach().flatten() for p in t.prep_model.parameters()] + [p.detach().flatten() for p in t.crnn_model.parameters()])
+    torch.save({"flat": flat, "topk": mine, "local": local, "reduced": reduced}, os.path.join(out, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gloo_world2(tmp_path):
+    port = 29500 + os.getpid() % 2000
+    mp.start_processes(_dp_worker, args=(2, port, str(tmp_path), str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["flat"], r1["flat"])                 # ranks stay in lock-step after A and B updates
+    # global TopK over the sharded CERs [0.1,0.9,0.3 | 0.2,0.4,0.3], k=3 -> 0.9 (rank0 idx1), 0.4 (rank1 idx1), 0.3 (rank0 idx2: ties rank-major)
+    assert r0["topk"].tolist() == [1, 2] and r1["topk"].tolist() == [1]
+
+    # specification: the exchanged gradient is the mean of the per-shard gradients, identical on all ranks
+    assert torch.equal(r0["reduced"], r1["reduced"])
+    assert torch.allclose(r0["reduced"], (r0["local"] + r1["local"]) / 2, rtol=1e-6, atol=1e-9)
+    assert not torch.equal(r0["local"], r1["local"])
