@@ -1,0 +1,65 @@
+"""The two trainers end to end on the MI355X HIP path (default backend), synthetic data + stub OCR."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(which, tmp, **over):
+    from qea.cli_flags import build_parser
+    a = build_parser(which, "").parse_args(["--exp_base_path", str(tmp), "--ocr", "stub", "--epoch", "1"])
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_area_trainer_hip(tmp_path):
+    from datasets.synthetic import SyntheticTextAreas
+    from train_nn_area import TrainNNPrep
+    tr = SyntheticTextAreas(32, seed=1, include_name=True, include_index=True)
+    cers_path = tmp_path / "cers.json"
+    json.dump({n: (i % 5) / 4 for i, n in enumerate(tr.names)}, open(cers_path, "w"))
+    args = _args("a", tmp_path / "exp", batch_size=16, minibatch_subset="topKCER", minibatch_subset_prop=0.75, cers_ocr_path=str(cers_path),
+                 inner_limit=2, inner_limit_skip=True, window_size=2)
+    t = TrainNNPrep(args, train_set=tr, val_set=SyntheticTextAreas(16, seed=2, include_name=True))
+    assert t.device.type == "cuda" and type(t.prep_model).__module__ == "models.model_unet"
+    p0 = torch.cat([p.detach().flatten().clone() for p in t.prep_model.parameters()])
+    c0 = torch.cat([p.detach().flatten().clone() for p in t.crnn_model.parameters()])
+    t.train()
+    p1 = torch.cat([p.detach().flatten() for p in t.prep_model.parameters()])
+    c1 = torch.cat([p.detach().flatten() for p in t.crnn_model.parameters()])
+    assert torch.isfinite(p1).all() and torch.isfinite(c1).all()
+    # Adam's first steps move every weight by about lr
+    assert 0 < (p1 - p0).abs().max().item() < 5 * 5e-5 * 2 + 1e-6 and 0 < (c1 - c0).abs().max().item() < 5 * 1e-4 * 2 + 1e-6
+    assert t.ocr.count_calls == 2 * 4 * 2 + 16
+    ck = tmp_path / "exp" / "ckpts"
+    prep = [f for f in os.listdir(ck) if f.startswith("Prep_model_0_")]
+    assert prep and os.path.exists(ck / "CRNN_model_0")
+    m = torch.load(ck / prep[0], weights_only=False)
+    assert type(m).__name__ == "UNet" and len(m.state_dict()) == len(t.prep_model.state_dict())
+
+
+def test_patch_trainer_hip(tmp_path):
+    from datasets.synthetic import SyntheticPatches
+    from train_nn_patch import TrainNNPrep
+    tr = SyntheticPatches(3, seed=1)
+    names = []
+    for i in range(len(tr)):
+        _, boxes, name = tr[i]
+        names += TrainNNPrep._strip_names([b["label"] for b in boxes], name)
+    cers_path = tmp_path / "cers.json"
+    json.dump({n: (i % 3) / 2 for i, n in enumerate(names)}, open(cers_path, "w"))
+    args = _args("p", tmp_path / "exp", minibatch_subset="topKCER", minibatch_subset_prop=0.5, cers_ocr_path=str(cers_path), inner_limit=2)
+    t = TrainNNPrep(args, train_set=tr, val_set=SyntheticPatches(1, seed=2, include_name=False))
+    t.train()
+    flat = torch.cat([p.detach().flatten() for p in t.prep_model.parameters()])
+    assert torch.isfinite(flat).all()
+    ck = tmp_path / "exp" / "ckpts"
+    for f in ("CRNN_model_0", "optim_prep_latest", "optim_crnn_latest"):
+        assert os.path.exists(ck / f)
+    st = torch.load(ck / "optim_prep_latest", weights_only=False)
+    assert len(st["state"]) == len(list(t.prep_model.parameters())) and "exp_avg" in st["state"][0]
+    assert set(json.load(open(tmp_path / "exp" / "cers" / "all_cers.json")).keys()) == set(names)
