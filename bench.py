@@ -172,6 +172,13 @@ def main():
     for k in prof:
         ops.prof_enable(k, False)
 
+    traffic = None                                   # HBM bytes per launch of the dominant kernel, from the committed PMC pass
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pm.get("batch_per_gpu") == B:
+            traffic = pm["conv_igemm"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -194,7 +201,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM: conv fwd/dgrad, "
                                                       "convT, LSTM/linear GEMMs)",
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "launches_per_step": ig["launches"] / args.steps,
+                         "traffic": traffic, "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_pmc_traffic.json",
+                         "algorithmic_bytes_per_launch": None, "launches_per_step": ig["launches"] / args.steps,
                          "ms_per_step_in_kernel": ig["ms"] / args.steps},
             "kernels": {
                 "conv_wgrad": {"tflops": wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0, "ms_per_step": wg["ms"] / args.steps,

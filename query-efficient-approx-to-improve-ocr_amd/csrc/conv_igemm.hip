@@ -142,22 +142,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
     const float* a_src = As + cur * BM * LDS_LD + (wm * TM + fr) * LDS_LD + fh * 4;
     const float* b_src = Bs + cur * BN * LDS_LD + (wn * TN + fr) * LDS_LD + fh * 4;
+    // fragment registers double-buffered over the four K-groups of the slice: the ds_reads of group
+    // kb+1 are in flight under the MFMAs of group kb (hipcc does not pipeline them on its own)
+    f32x4 af[2][MI], bf[2][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(a_src + i * 32 * LDS_LD);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(b_src + j * 32 * LDS_LD);
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
-      f32x4 af[MI], bf[NJ];
+      const int c = kb & 1, n = c ^ 1;
+      if (kb + 1 < BK / 8) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[i] = *reinterpret_cast<const f32x4*>(a_src + i * 32 * LDS_LD + kb * 8);
+        for (int i = 0; i < MI; ++i) af[n][i] = *reinterpret_cast<const f32x4*>(a_src + i * 32 * LDS_LD + (kb + 1) * 8);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        bf[j] = *reinterpret_cast<const f32x4*>(b_src + j * 32 * LDS_LD + kb * 8);
+        for (int j = 0; j < NJ; ++j) bf[n][j] = *reinterpret_cast<const f32x4*>(b_src + j * 32 * LDS_LD + (kb + 1) * 8);
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i][s], bf[c][j][s], acc[i][j], 0, 0, 0);
+      // pin the interleave: one LDS fragment read of the next group per (4*MI*NJ / (MI+NJ)) MFMAs of this one
+      if (kb + 1 < BK / 8) {
+#pragma unroll
+        for (int r = 0; r < MI + NJ; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, (4 * MI * NJ) / (MI + NJ), 0);
+        }
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MI * NJ, 0);
+      }
     }
 
     if (kt + 1 < KT) stage(cur ^ 1);
