@@ -254,6 +254,137 @@ int launch(const ConvArgs& a, hipStream_t s) {
   return QEA_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / pad 1 / stride 1 convolution for the NARROW layers (C_in, C_out in {32, 64}: UNet levels 1-2,
+// forward and input-gradient).  With N = 32..64 the generic kernel re-gathers every input pixel 9x
+// through LDS for only 32..64 output channels (16-32 flop per gathered byte: L2-bound).  Here a
+// workgroup owns a TH x 32 pixel tile of one image: the (TH+2) x 34 input halo is loaded ONCE into LDS
+// (pixel stride C_in+4 floats: conflict-free ds_read_b128) and all 9 taps read their A fragments from it
+// with shifted addresses; filter fragments come straight from global memory (<= 147 KB, L1/L2-resident),
+// so after the single barrier the four waves never synchronise again.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int TH>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ y, int B, int H, int W, int ldx, int ldy) {
+  constexpr int TW = 32, PS = CIN + 4, HW_ = TW + 2, HH = TH + 2;
+  constexpr int MI = TH / 4, NJ = COUT / 32, KC = CIN / 32;
+  extern __shared__ __attribute__((aligned(16))) float halo[];  // [HH][HW_][PS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+
+  // ---- halo load (zero outside the image) ----
+  constexpr int C4 = CIN / 4;
+  const float* xb = x + (size_t)b * H * W * ldx;
+  for (int e = tid; e < HH * HW_ * C4; e += 256) {
+    const int c4 = e % C4;
+    const int q = e / C4;
+    const int hx = q % HW_, hy = q / HW_;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      v = *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * ldx + c4 * 4);
+    *reinterpret_cast<f32x4*>(halo + q * PS + c4 * 4) = v;
+  }
+  __syncthreads();
+
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // filter rows of this lane: w[n][tap][c], n = j*32 + fr
+  const float* wl = w + (size_t)fr * 9 * CIN + fh * 4;
+  constexpr int KSTEPS = 9 * KC;
+  f32x4 bq[2][4][NJ];  // [buffer][kb][j]
+  auto load_b = [&](int ks, int buf) {
+    const int tap = ks / KC, c0 = (ks % KC) * 32;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        bq[buf][kb][j] = *reinterpret_cast<const f32x4*>(wl + (size_t)j * 32 * 9 * CIN + tap * CIN + c0 + kb * 8);
+  };
+  load_b(0, 0);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < KSTEPS) load_b(ks + 1, cur ^ 1);
+    const int tap = ks / KC, c0 = (ks % KC) * 32;
+    const int kh = tap / 3, kw = tap % 3;
+    const float* a_src = halo + ((wave * MI + kh) * HW_ + fr + kw) * PS + c0 + fh * 4;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x4 af[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_src + i * HW_ * PS + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bq[cur][kb][j][s], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- store: row (= pixel x) = (r&3) + 8*(r>>2) + 4*fh, col (= channel) = fr ----
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float* yrow = y + ((size_t)(b * H + y0 + wave * MI + i) * W + x0) * ldy;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) yrow[(size_t)px * ldy + j * 32 + fr] = acc[i][j][r];
+    }
+  }
+}
+
+template <int CIN, int COUT, int TH>
+int launch_halo(const ConvArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)(TH + 2) * 34 * (CIN + 4) * sizeof(float);
+  auto kern = conv3x3_halo_kernel<CIN, COUT, TH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const long long grid = (long long)a.B * (a.H / TH) * (a.W / 32);
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    qea_set_error("qea_conv_igemm(halo): grid %lld out of range", grid);
+    return QEA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, a.w, a.y, a.B, a.H, a.W, a.ldx, a.ldy);
+  return QEA_OK;
+}
+
+bool halo_eligible(const qea_conv_desc* d) {
+  const bool ch = (d->Cin == 32 || d->Cin == 64) && (d->N == 32 || d->N == 64);
+  const int th = d->Cin == 32 ? 8 : 4;
+  return ch && d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H &&
+         d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->scale && !d->bias && !d->mask &&
+         !d->relu && !d->accumulate && d->ldy % 1 == 0;
+}
+
+int launch_halo_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  if (d->Cin == 32 && d->N == 32) return launch_halo<32, 32, 8>(a, s);
+  if (d->Cin == 32 && d->N == 64) return launch_halo<32, 64, 8>(a, s);
+  if (d->Cin == 64 && d->N == 32) return launch_halo<64, 32, 4>(a, s);
+  return launch_halo<64, 64, 4>(a, s);
+}
+
 }  // namespace
 
 extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
@@ -286,10 +417,15 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
 
   hipStream_t s = (hipStream_t)stream;
   int tile = d->tile;
-  if (tile == 0) tile = (d->N <= 32) ? 3 : (d->N <= 64) ? 2 : 1;
+  if (tile == 0) tile = halo_eligible(d) ? 4 : (d->N <= 32) ? 3 : (d->N <= 64) ? 2 : 1;
+  if (tile == 4 && !halo_eligible(d)) {
+    qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, plain epilogue");
+    return QEA_ERR_INVALID;
+  }
   qea_prof_begin(QEA_PROF_CONV_IGEMM, s);
   int rc;
   switch (tile) {
+    case 4: rc = launch_halo_any(d, a, s); break;
     case 1: rc = launch<128, 128, 2, 2>(a, s); break;
     case 2: rc = launch<256, 64, 4, 1>(a, s); break;
     case 3: rc = launch<256, 32, 4, 1>(a, s); break;

@@ -188,16 +188,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n4, int splits,
+// out[g][i] = sum_{k in group g} ws[k][i]   (float4 elements; group g = blockIdx.y covers `gs` slabs).
+// With gridDim.y == 1 and gs >= splits this is the plain final reduction into dW.
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n4, int splits, int gs,
                                      long long slab4, int accumulate) {
   const f32x4* w4 = reinterpret_cast<const f32x4*>(ws);
-  f32x4* d4 = reinterpret_cast<f32x4*>(dw);
+  f32x4* d4 = reinterpret_cast<f32x4*>(out) + (size_t)blockIdx.y * slab4;
+  const int k0 = blockIdx.y * gs;
+  const int k1 = min(splits, k0 + gs);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    f32x4 s = w4[i];
-    for (int k = 1; k < splits; ++k) s += w4[i + k * slab4];
+    f32x4 s = w4[i + (size_t)k0 * slab4];
+    for (int k = k0 + 1; k < k1; ++k) s += w4[i + (size_t)k * slab4];
     if (accumulate) s += d4[i];
     d4[i] = s;
   }
+}
+
+constexpr int REDUCE_GROUP = 32;
+
+// order-fixed reduction of `splits` slabs into dw; more than 64 slabs go through one level of group partials
+// (stored behind the slabs in the workspace) so that no thread walks thousands of dependent loads
+void reduce_slabs(float* ws, float* dw, long long n4, int splits, int accumulate, hipStream_t s) {
+  int grid = (int)((n4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (splits <= 64) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)ws, dw, n4, splits, splits, n4, accumulate);
+    return;
+  }
+  const int groups = (splits + REDUCE_GROUP - 1) / REDUCE_GROUP;
+  float* ws2 = ws + (size_t)splits * n4 * 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid, groups), dim3(256), 0, s, (const float*)ws, ws2, n4, splits, REDUCE_GROUP, n4, 0);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)ws2, dw, n4, groups, groups, n4, accumulate);
+}
+
+size_t slab_workspace_bytes(size_t slab_floats, int splits) {
+  size_t b = (size_t)splits * slab_floats * sizeof(float);
+  if (splits > 64) b += (size_t)((splits + REDUCE_GROUP - 1) / REDUCE_GROUP) * slab_floats * sizeof(float);
+  return b;
 }
 
 struct Plan {
@@ -270,20 +297,189 @@ int validate(const qea_wgrad_desc* d, const char* who) {
   return QEA_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the NARROW 3x3 layers (R, C in {32, 64}: UNet levels 1-2).  The per-tap kernel above
+// re-reads P and Q nine times for 2*R*C flops per (R+C)*4 bytes — the PMC pass shows 4.7x the algorithmic
+// HBM traffic.  Here a workgroup walks TH x 32 pixel tiles: P tile and the (TH+2) x 34 Q halo go to LDS
+// ONCE and every wave accumulates ALL NINE taps (9 accumulator tiles) from it: waves split the (R/32 x
+// C/32) channel blocks and, when those are fewer than 4, the tile's rows.  Each (workgroup, row-split)
+// writes one partial slab; the order-fixed splitk_reduce pass sums them.
+// ---------------------------------------------------------------------------------------------
+template <int R, int C, int TH>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                         float* __restrict__ ws, int B, int H, int W, int ldp, int ldq,
+                                                         int n_tiles) {
+  constexpr int WR = R / 32, WC = C / 32, WK = 4 / (WR * WC), ROWS = TH / WK;
+  constexpr int HW_ = 34, HH = TH + 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ps = smem;                  // [TH*32][R]
+  float* Qs = smem + TH * 32 * R;    // [HH*34][C]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WR * WC), wrc = wave % (WR * WC), wr = wrc / WC, wc = wrc % WC;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int tiles_x = W / 32, tiles_y = H / TH;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // tile t+1's P tile and Q halo are fetched into registers while the MFMAs of tile t run (single LDS buffer)
+  constexpr int NP = (TH * 32 * (R / 4) + 255) / 256;
+  constexpr int NQ = (HH * HW_ * (C / 4) + 255) / 256;
+  f32x4 preg[NP], qreg[NQ];
+  auto fetch = [&](int tile) {
+    const int tx = tile % tiles_x;
+    const int ty = (tile / tiles_x) % tiles_y;
+    const int b = tile / (tiles_x * tiles_y);
+    const int x0 = tx * 32, y0 = ty * TH;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int e = tid + 256 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < TH * 32 * (R / 4)) {
+        const int c4 = e % (R / 4), pix = e / (R / 4);
+        v = *reinterpret_cast<const f32x4*>(p + ((size_t)(b * H + y0 + (pix >> 5)) * W + x0 + (pix & 31)) * ldp + c4 * 4);
+      }
+      preg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + 256 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < HH * HW_ * (C / 4)) {
+        const int c4 = e % (C / 4), hq = e / (C / 4);
+        const int iy = y0 + hq / HW_ - 1, ix = x0 + hq % HW_ - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+          v = *reinterpret_cast<const f32x4*>(q + ((size_t)(b * H + iy) * W + ix) * ldq + c4 * 4);
+      }
+      qreg[i] = v;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int e = tid + 256 * i;
+      if (e < TH * 32 * (R / 4)) *reinterpret_cast<f32x4*>(Ps + e * 4) = preg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + 256 * i;
+      if (e < HH * HW_ * (C / 4)) *reinterpret_cast<f32x4*>(Qs + e * 4) = qreg[i];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed
+    stage();
+    __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int py = wk * ROWS + rr;
+      const float* pa = Ps + (py * 32 + fh) * R + wr * 32 + fr;
+      const float* qb = Qs + (py * HW_ + fh) * C + wc * 32 + fr;
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const float af = pa[(2 * s) * R];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float bf = qb[((kh * HW_) + 2 * s + kw) * C];
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[kh * 3 + kw], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // partial slab of this (workgroup, row-split): [R][9][C]
+  float* out = ws + ((size_t)blockIdx.x * WK + wk) * (R * 9 * C);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      out[((size_t)rr * 9 + t) * C + wc * 32 + fr] = acc[t][r];
+    }
+}
+
+struct HaloPlan {
+  bool ok;
+  int th, wk, n_tiles, grid;
+};
+
+HaloPlan halo_plan(const qea_wgrad_desc* d) {
+  HaloPlan h = {false, 0, 0, 0, 0};
+  const bool ch = (d->R == 32 || d->R == 64) && (d->C == 32 || d->C == 64);
+  if (!ch || d->KH != 3 || d->KW != 3 || d->pad_h != 1 || d->pad_w != 1 || d->stride_h != 1 || d->stride_w != 1 || d->PH != d->QH ||
+      d->PW != d->QW || d->PW % 32)
+    return h;
+  h.th = (d->R == 32 && d->C == 32) ? 8 : (d->R + d->C <= 96) ? 4 : 2;
+  if (d->PH % h.th) return h;
+  h.wk = 4 / ((d->R / 32) * (d->C / 32));
+  const long long nt = (long long)d->B * (d->PH / h.th) * (d->PW / 32);
+  if (nt > 0x7fffffffLL) return h;
+  h.n_tiles = (int)nt;
+  h.grid = h.n_tiles < 768 ? h.n_tiles : 768;
+  h.ok = true;
+  return h;
+}
+
+template <int R, int C, int TH>
+void launch_halo(const qea_wgrad_desc* d, const HaloPlan& h, hipStream_t s) {
+  constexpr size_t lds = ((size_t)TH * 32 * R + (size_t)(TH + 2) * 34 * C) * sizeof(float);
+  auto kern = wgrad_halo_kernel<R, C, TH>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(h.grid), dim3(256), lds, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->ldp, d->ldq, h.n_tiles);
+}
+
 }  // namespace
 
 extern "C" size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d) {
   if (!d || d->R <= 0 || d->C <= 0 || d->B <= 0) return 0;
+  if (d->tile == 0 || d->tile == 6) {
+    const HaloPlan h = halo_plan(d);
+    if (h.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h.grid * h.wk);
+  }
   const Plan p = make_plan(d);
   if (p.splits <= 1) return 0;
-  return (size_t)p.splits * d->R * d->KH * d->KW * d->C * sizeof(float);
+  return slab_workspace_bytes((size_t)d->R * d->KH * d->KW * d->C, p.splits);
 }
 
 extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
   int rc = validate(d, "qea_conv_wgrad");
   if (rc != QEA_OK) return rc;
+  if (d->tile == 0 || d->tile == 6) {
+    const HaloPlan h = halo_plan(d);
+    if (h.ok) {
+      const size_t slab = (size_t)d->R * 9 * d->C;
+      const size_t need_h = slab_workspace_bytes(slab, h.grid * h.wk);
+      QEA_REQUIRE(d->workspace && d->workspace_bytes >= need_h && ((uintptr_t)d->workspace & 15) == 0,
+                  "qea_conv_wgrad: workspace of %zu bytes required, %zu given", need_h, (size_t)d->workspace_bytes);
+      hipStream_t hs = (hipStream_t)stream;
+      qea_prof_begin(QEA_PROF_CONV_WGRAD, hs);
+      if (d->R == 32 && d->C == 32) launch_halo<32, 32, 8>(d, h, hs);
+      else if (d->R == 32 && d->C == 64) launch_halo<32, 64, 4>(d, h, hs);
+      else if (d->R == 64 && d->C == 32) launch_halo<64, 32, 4>(d, h, hs);
+      else launch_halo<64, 64, 2>(d, h, hs);
+      reduce_slabs((float*)d->workspace, d->dw, (long long)slab / 4, h.grid * h.wk, d->accumulate, hs);
+      qea_prof_end(QEA_PROF_CONV_WGRAD, hs, 2.0 * d->B * d->PH * (double)d->PW * (double)slab, 0.0);
+      QEA_CHECK_LAUNCH();
+      return QEA_OK;
+    }
+    QEA_REQUIRE(d->tile == 0, "qea_conv_wgrad: tile 6 (LDS-halo) needs a 3x3 pad-1 stride-1 conv with R,C in {32,64}, PW %% 32 == 0");
+  }
   const Plan p = make_plan(d);
-  const size_t need = (p.splits > 1) ? (size_t)p.splits * d->R * d->KH * d->KW * d->C * sizeof(float) : 0;
+  const size_t need = (p.splits > 1) ? slab_workspace_bytes((size_t)d->R * d->KH * d->KW * d->C, p.splits) : 0;
   QEA_REQUIRE(need == 0 || (d->workspace && d->workspace_bytes >= need && ((uintptr_t)d->workspace & 15) == 0),
               "qea_conv_wgrad: workspace of %zu bytes required, %zu given", need, (size_t)d->workspace_bytes);
 
@@ -309,13 +505,7 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     case 5: launch<64, 32, 1, 1, 4>(a, s); break;
     default: qea_set_error("qea_conv_wgrad: unknown tile %d", p.tile); return QEA_ERR_INVALID;
   }
-  if (p.splits > 1) {
-    const long long n4 = a.slab / 4;
-    int grid = (int)((n4 + 255) / 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)d->workspace, d->dw, n4, p.splits,
-                       a.slab / 4, d->accumulate);
-  }
+  if (p.splits > 1) reduce_slabs((float*)d->workspace, d->dw, a.slab / 4, p.splits, d->accumulate, s);
   qea_prof_end(QEA_PROF_CONV_WGRAD, s, 2.0 * a.M * (double)a.slab, 0.0);
   QEA_CHECK_LAUNCH();
   return QEA_OK;

@@ -68,3 +68,24 @@ def test_conv_2x2_stride2():
 
 def test_gemm_1x1():
     _run(1, 1, 300, 512, 95, 1, 1, 0, bias=True)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W", [(32, 32, 8, 32), (32, 64, 16, 64), (64, 32, 4, 32), (64, 64, 12, 96)])
+def test_conv3x3_halo_kernel_strided_buffers(Cin, Cout, H, W):
+    """tile 4 = LDS-halo kernel of the narrow layers, reading from / writing into wider (concat) buffers."""
+    from qea import ops
+    B = 3
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    ldx, ldy = Cin + 32, Cout + 64
+    xb = torch.full((B, H, W, ldx), 7.0, device="cuda")
+    xb[..., 32:] = x.permute(0, 2, 3, 1).cuda()
+    yb = torch.full((B, H, W, ldy), -3.0, device="cuda")
+    ops.conv_igemm(xb[..., 32:], w.permute(0, 2, 3, 1).contiguous().cuda(), yb[..., 64:], B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout,
+                   KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=ldy, tile=4)
+    torch.cuda.synchronize()
+    got = yb[..., 64:].cpu().permute(0, 3, 1, 2).double()
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert (yb[..., :64] == -3.0).all()
