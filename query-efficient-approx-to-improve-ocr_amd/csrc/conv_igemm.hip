@@ -26,15 +26,17 @@ struct ConvArgs {
   int M, K, n_tiles, m_tiles;
 };
 
-constexpr int BK = 32;      // K-slice per stage (floats)
-constexpr int LDS_LD = 36;  // padded LDS row (floats): 144 B keeps b128 reads conflict-free
+constexpr int BK_MIN = 16;  // Cin must be a multiple of 32 (checked by the entry point); K-slice is 16 or 32
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int LDS_LD = BK + 4;               // padded LDS row (floats): keeps b128 reads conflict-free
+  constexpr int KCH = BK / 4;                  // float4 per row of a K-slice
+  constexpr int RPP = 256 / KCH;               // rows covered per pass of the 256 threads
   constexpr int TM = BM / WGM, TN = BN / WGN;  // wave tile
   constexpr int MI = TM / 32, NJ = TN / 32;    // 32x32 accumulator tiles per wave
-  constexpr int A_LD = BM / 32;                // float4 gathers per thread per stage (A)
-  constexpr int B_LD = BN / 32;                // (B)
+  constexpr int A_LD = BM / RPP;               // float4 gathers per thread per stage (A)
+  constexpr int B_LD = BN / RPP;               // (B)
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -53,14 +55,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-thread gather coordinates (fixed over the K loop) ----
-  const int lrow = tid >> 3;  // 0..31
-  const int kc = tid & 7;     // which float4 of the 32-float K-slice
+  const int lrow = tid / KCH;  // 0..RPP-1
+  const int kc = tid % KCH;    // which float4 of the K-slice
   int a_pix[A_LD];            // b*H*W, or -1 when the row is past M
   int a_ih0[A_LD], a_iw0[A_LD];
   const int ohw = p.OH * p.OW;
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
-    const int m = m0 + lrow + 32 * i;
+    const int m = m0 + lrow + RPP * i;
     if (m < p.M) {
       const int b = m / ohw;
       const int rem = m - b * ohw;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const float* b_ptr[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
-    const int n = n0 + lrow + 32 * j;
+    const int n = n0 + lrow + RPP * j;
     b_ptr[j] = (n < p.N) ? (p.w + (size_t)n * p.K + kc * 4) : nullptr;
   }
 
@@ -115,10 +117,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     float* b_dst = Bs + buf * BN * LDS_LD;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<f32x4*>(a_dst + (lrow + 32 * i) * LDS_LD + kc * 4) = a_reg[i];
+      *reinterpret_cast<f32x4*>(a_dst + (lrow + RPP * i) * LDS_LD + kc * 4) = a_reg[i];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
-      *reinterpret_cast<f32x4*>(b_dst + (lrow + 32 * j) * LDS_LD + kc * 4) = b_reg[j];
+      *reinterpret_cast<f32x4*>(b_dst + (lrow + RPP * j) * LDS_LD + kc * 4) = b_reg[j];
   };
 
   f32x16 acc[MI][NJ];
@@ -233,13 +235,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int BK>
 int launch(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.m_tiles = qea_cdiv(p.M, BM);
   p.n_tiles = qea_cdiv(p.N, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-  auto kern = conv_igemm_kernel<BM, BN, WGM, WGN>;
+  const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+  auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, BK>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -391,7 +393,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   QEA_REQUIRE(d && d->x && d->w && d->y, "qea_conv_igemm: null pointer");
   QEA_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0 && d->N > 0,
               "qea_conv_igemm: non-positive dimension");
-  QEA_REQUIRE(d->Cin > 0 && d->Cin % BK == 0, "qea_conv_igemm: Cin=%d must be a multiple of %d", d->Cin, BK);
+  QEA_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, "qea_conv_igemm: Cin=%d must be a multiple of 32", d->Cin);
   QEA_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride_h > 0 && d->stride_w > 0, "qea_conv_igemm: bad filter/stride");
   QEA_REQUIRE(d->ldx >= d->Cin && d->ldx % 4 == 0, "qea_conv_igemm: ldx=%d must be >= Cin and a multiple of 4", d->ldx);
   QEA_REQUIRE(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "qea_conv_igemm: x/w must be 16-byte aligned");
@@ -417,7 +419,12 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
 
   hipStream_t s = (hipStream_t)stream;
   int tile = d->tile;
-  if (tile == 0) tile = halo_eligible(d) ? 4 : (d->N <= 32) ? 3 : (d->N <= 64) ? 2 : 1;
+  if (tile == 0) {
+    // measured on MI355X (tools/bench_conv.py): the 16-deep K-slice (half the LDS, 4 workgroups per CU) wins
+    // only when the grid is large enough to keep all of them busy
+    const long long tiles128 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 128);
+    tile = halo_eligible(d) ? 4 : (d->N <= 32) ? 3 : (d->N <= 64) ? 2 : (tiles128 >= 2048) ? 5 : 1;
+  }
   if (tile == 4 && !halo_eligible(d)) {
     qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, plain epilogue");
     return QEA_ERR_INVALID;
@@ -426,9 +433,10 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   int rc;
   switch (tile) {
     case 4: rc = launch_halo_any(d, a, s); break;
-    case 1: rc = launch<128, 128, 2, 2>(a, s); break;
-    case 2: rc = launch<256, 64, 4, 1>(a, s); break;
-    case 3: rc = launch<256, 32, 4, 1>(a, s); break;
+    case 1: rc = launch<128, 128, 2, 2, 32>(a, s); break;
+    case 2: rc = launch<256, 64, 4, 1, 32>(a, s); break;
+    case 3: rc = launch<256, 32, 4, 1, 32>(a, s); break;
+    case 5: rc = launch<128, 128, 2, 2, 16>(a, s); break;
     default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
   }
   if (rc != QEA_OK) return rc;

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   constexpr int Q_LD = BC / 32;
   constexpr int STEPS = (BKP / 2) / WK;  // MFMA k-steps per wave per stage
   static_assert(WR * WC * WK == 4, "4 waves");
+  static_assert(MI <= 2 && NJ <= 2, "fragment reads are b32 / b64");
   constexpr int STAGE_FLOATS = BKP * (BR + BC);
   constexpr int RED_FLOATS = (WK > 1) ? WK * BR * BC : 0;
 
@@ -122,15 +123,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   for (int st = 0; st < nstage; ++st) {
     const int cur = st & 1;
     if (st + 1 < nstage) gather(m_begin + (st + 1) * BKP);
-    const float* ps = Ps + cur * BKP * BR + (wk * (BKP / WK) + fh) * BR + wr * TR + fr;
-    const float* qs = Qs + cur * BKP * BC + (wk * (BKP / WK) + fh) * BC + wc * TCc + fr;
+    // fragment reads: a lane takes MI (NJ) CONSECUTIVE channels with one ds_read_b32/b64 and feeds them to
+    // MI (NJ) different accumulator tiles, i.e. tile i holds channels {MI*row + i} of the wave's block
+    // (interleaved, undone in the epilogue) — half the LDS instructions of one read per tile.
+    const float* ps = Ps + cur * BKP * BR + (wk * (BKP / WK) + fh) * BR + wr * TR + fr * MI;
+    const float* qs = Qs + cur * BKP * BC + (wk * (BKP / WK) + fh) * BC + wc * TCc + fr * NJ;
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       float af[MI], bf[NJ];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = ps[s * 2 * BR + i * 32];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = qs[s * 2 * BC + j * 32];
+      if constexpr (MI == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(ps + s * 2 * BR);
+        af[0] = t.x;
+        af[1] = t.y;
+      } else {
+        af[0] = ps[s * 2 * BR];
+      }
+      if constexpr (NJ == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(qs + s * 2 * BC);
+        bf[0] = t.x;
+        bf[1] = t.y;
+      } else {
+        bf[0] = qs[s * 2 * BC];
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -153,8 +167,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int rr = wr * TR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          const int cc = wc * TCc + j * 32 + fr;
+          const int rr = wr * TR + MI * ((r & 3) + 8 * (r >> 2) + 4 * fh) + i;
+          const int cc = wc * TCc + NJ * fr + j;
           red[(wk * BR + rr) * BC + cc] = acc[i][j][r];
         }
     __syncthreads();
@@ -176,8 +190,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int rr = r0 + wr * TR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          const int cc = c0 + wc * TCc + j * 32 + fr;
+          const int rr = r0 + wr * TR + MI * ((r & 3) + 8 * (r >> 2) + 4 * fh) + i;
+          const int cc = c0 + wc * TCc + NJ * fr + j;
           if (rr < a.R && cc < a.C) {
             const size_t o = (size_t)rr * ktot + tap * a.C + cc;
             float v = acc[i][j][r];
