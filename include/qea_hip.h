@@ -47,6 +47,8 @@ const char* qea_last_error(void);
 int qea_prof_enable(int klass, int on);
 int qea_prof_reset(void);
 int qea_prof_read(int klass, double* ms, double* flops, double* bytes, int64_t* launches);
+/* per-launch view of the same records (in launch order): up to `capacity` entries, *count = recorded launches */
+int qea_prof_read_launches(int klass, double* ms, double* flops, int64_t capacity, int64_t* count);
 
 /* ------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).

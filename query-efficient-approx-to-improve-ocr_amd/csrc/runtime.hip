@@ -12,6 +12,7 @@ struct ProfClass {
   std::vector<hipEvent_t> start, stop;  // event pool, reused across resets
   size_t used = 0;
   double flops = 0.0, bytes = 0.0;
+  std::vector<double> launch_flops;
   bool open = false;
 };
 ProfClass g_prof[QEA_PROF_NCLASS];
@@ -48,6 +49,7 @@ void qea_prof_end(int klass, hipStream_t s, double flops, double bytes) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   hipEventRecord(pc.stop[pc.used], s);
   pc.used++;
+  pc.launch_flops.push_back(flops);
   pc.flops += flops;
   pc.bytes += bytes;
   pc.open = false;
@@ -63,6 +65,7 @@ extern "C" int qea_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& pc : g_prof) {
     pc.used = 0;
+    pc.launch_flops.clear();
     pc.flops = pc.bytes = 0.0;
     pc.open = false;
   }
@@ -87,5 +90,23 @@ extern "C" int qea_prof_read(int klass, double* ms, double* flops, double* bytes
   if (flops) *flops = pc.flops;
   if (bytes) *bytes = pc.bytes;
   if (launches) *launches = (int64_t)pc.used;
+  return QEA_OK;
+}
+
+extern "C" int qea_prof_read_launches(int klass, double* ms, double* flops, int64_t capacity, int64_t* count) {
+  QEA_REQUIRE(klass >= 0 && klass < QEA_PROF_NCLASS && count, "qea_prof_read_launches: bad arguments");
+  ProfClass& pc = g_prof[klass];
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  *count = (int64_t)pc.used;
+  for (size_t i = 0; i < pc.used && (int64_t)i < capacity; ++i) {
+    if (hipEventSynchronize(pc.stop[i]) != hipSuccess) {
+      qea_set_error("qea_prof_read_launches: event sync failed");
+      return QEA_ERR_LAUNCH;
+    }
+    float t = 0.f;
+    hipEventElapsedTime(&t, pc.start[i], pc.stop[i]);
+    if (ms) ms[i] = t;
+    if (flops) flops[i] = pc.launch_flops[i];
+  }
   return QEA_OK;
 }

@@ -223,3 +223,13 @@ def crop_pad_scatter(dout, boxes, N, OH, OW, dimg, H, W):
 def greedy_decode(scores, ld_t, ld_n, T, N, C_, blank, tokens, lengths):
     _lib.check(_lib.lib().qea_greedy_decode(_ptr(scores), ld_t, ld_n, T, N, C_, blank, _ptr(tokens), _ptr(lengths), _stream()),
                "qea_greedy_decode")
+
+
+def prof_read_launches(klass, capacity=4096):
+    import numpy as np
+    ms = np.zeros(capacity)
+    fl = np.zeros(capacity)
+    n = C.c_int64()
+    _lib.check(_lib.lib().qea_prof_read_launches(klass, ms.ctypes.data, fl.ctypes.data, capacity, C.byref(n)), "qea_prof_read_launches")
+    k = min(n.value, capacity)
+    return ms[:k], fl[:k]
