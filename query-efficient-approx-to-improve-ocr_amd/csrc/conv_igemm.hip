@@ -423,7 +423,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     // measured on MI355X (tools/bench_conv.py): the 16-deep K-slice (half the LDS, 4 workgroups per CU) wins
     // only when the grid is large enough to keep all of them busy
     const long long tiles128 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 128);
-    tile = halo_eligible(d) ? 4 : (d->N <= 32) ? 3 : (d->N <= 64) ? 2 : (tiles128 >= 2048) ? 5 : 1;
+    tile = halo_eligible(d) ? 4 : (d->N <= 32) ? 3 : (d->N <= 64) ? 2 : (tiles128 >= 2048) ? 5 : (tiles128 < 192) ? 6 : 1;
   }
   if (tile == 4 && !halo_eligible(d)) {
     qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, plain epilogue");
@@ -437,6 +437,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 2: rc = launch<256, 64, 4, 1, 32>(a, s); break;
     case 3: rc = launch<256, 32, 4, 1, 32>(a, s); break;
     case 5: rc = launch<128, 128, 2, 2, 16>(a, s); break;
+    case 6: rc = launch<128, 64, 2, 2, 32>(a, s); break;   // small grids: twice the workgroups of tile 1
     default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
   }
   if (rc != QEA_OK) return rc;

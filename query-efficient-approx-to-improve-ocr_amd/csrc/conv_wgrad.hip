@@ -253,6 +253,8 @@ Plan make_plan(const qea_wgrad_desc* d) {
   int tile = d->tile;
   if (tile == 0) {
     if (R >= 128 && C >= 128) tile = 1;
+    else if (R >= 128 && C == 64) tile = 7;
+    else if (R == 64 && C >= 128) tile = 8;
     else if (R <= 32 && C <= 32) tile = 3;
     else if (R <= 32) tile = 4;
     else if (C <= 32) tile = 5;
@@ -264,6 +266,8 @@ Plan make_plan(const qea_wgrad_desc* d) {
     case 2: p.br = 64; p.bc = 64; break;
     case 3: p.br = 32; p.bc = 32; break;
     case 4: p.br = 32; p.bc = 64; break;
+    case 7: p.br = 128; p.bc = 64; break;
+    case 8: p.br = 64; p.bc = 128; break;
     default: p.br = 64; p.bc = 32; break;
   }
   p.r_tiles = qea_cdiv(R, p.br);
@@ -517,6 +521,8 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     case 3: launch<32, 32, 1, 1, 4>(a, s); break;
     case 4: launch<32, 64, 1, 1, 4>(a, s); break;
     case 5: launch<64, 32, 1, 1, 4>(a, s); break;
+    case 7: launch<128, 64, 2, 2, 1>(a, s); break;
+    case 8: launch<64, 128, 2, 2, 1>(a, s); break;
     default: qea_set_error("qea_conv_wgrad: unknown tile %d", p.tile); return QEA_ERR_INVALID;
   }
   if (p.splits > 1) reduce_slabs((float*)d->workspace, d->dw, a.slab / 4, p.splits, d->accumulate, s);
