@@ -121,3 +121,33 @@ def test_cli_flag_surface():
     assert p.random_std is True and p.ocr == "Tesseract" and p.weightgen_method == "decaying" and p.decay_factor == 0.7
     a = build_parser("a", "").parse_args(["--minibatch_subset", "topKCER", "--random_std", "--lr_scheduler", "cosine"])
     assert a.batch_size == 32 and a.epoch == 50 and a.random_std is False and not hasattr(a, "weight_decay")
+
+
+def test_file_datasets_roundtrip(tmp_path):
+    """on-disk formats of the reference's datasets (datasets/img_dataset.py, patch_dataset.py)."""
+    from PIL import Image
+    from datasets._io import to_tensor
+    from datasets.img_dataset import ImgDataset
+    from datasets.patch_dataset import PatchDataset
+    from transform_helper import PadWhite
+    d = tmp_path / "vgg_train"
+    d.mkdir()
+    rng = np.random.RandomState(0)
+    for i, lab in enumerate(["hello", "A1", "x" * 101]):
+        Image.fromarray((rng.rand(20, 60) * 255).astype(np.uint8)).save(d / f"{i}_{lab}_w.png")
+    ds = ImgDataset(str(d), transform=lambda im: to_tensor(PadWhite((32, 128))(im)), include_name=True, include_index=True)
+    assert len(ds) == 2                                   # the 101-char label is dropped
+    img, label, name, idx = ds[0]
+    assert img.shape == (1, 32, 128) and label in ("hello", "A1") and name.endswith("_w.png") and idx == 0
+    assert img[0, 0, 0] == 1.0 and img.min() < 1.0        # white padding around the strip
+    p = tmp_path / "patch_dataset_train" / "folderA"
+    p.mkdir(parents=True)
+    Image.fromarray((rng.rand(100, 300) * 255).astype(np.uint8)).save(p / "doc1.png")
+    boxes = [dict(label="ab", x_min=10, y_min=5, x_max=90, y_max=30), dict(label="wide", x_min=0, y_min=0, x_max=200, y_max=20)]
+    json.dump(boxes, open(p / "doc1.json", "w"))
+    pd = PatchDataset(str(tmp_path / "patch_dataset_train"), pad=True, include_name=True)
+    image, labels, name = pd[0]
+    assert image.shape == (1, 400, 512) and len(labels) == 1 and labels[0]["label"] == "ab"
+    assert (labels[0]["x_min"], labels[0]["y_min"]) == (10 + 106, 5 + 150)      # centred on the 400x512 canvas
+    batch = PatchDataset.collate([pd[0]])
+    assert batch[0].shape == (1, 1, 400, 512) and batch[2][0].endswith("doc1.png")
