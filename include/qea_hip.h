@@ -252,6 +252,13 @@ int qea_crop_pad_scatter(const float* dout, const int32_t* boxes, int32_t N, int
 int qea_greedy_decode(const float* scores, int32_t ld_t, int32_t ld_n, int32_t T, int32_t N, int32_t C, int32_t blank,
                       int32_t* tokens, int32_t* lengths, void* stream);
 
+/* Unit-cost edit distance between the greedy decode of each sample (pred_tokens [N][ldp], pred_len)
+ * and its ground-truth token string (concatenated gt_tokens, gt_offsets, gt_len): the numerator of
+ * utils.compare_labels' CER (utils.py:95-110, python-Levenshtein `distance`); the host divides by
+ * max(1, len(gt)) in float64 as the reference does.  ldp <= 128. */
+int qea_edit_distance(const int32_t* pred_tokens, int32_t ldp, const int32_t* pred_len, const int32_t* gt_tokens,
+                      const int64_t* gt_offsets, const int32_t* gt_len, int32_t N, int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,6 +200,36 @@ __global__ __launch_bounds__(64) void greedy_decode_kernel(const float* __restri
   if (lane == 0) lengths[n] = len;
 }
 
+// ------------------------------------------------------------------ edit distance (CER numerator)
+// one thread per sample, the DP row in LDS column-major (row[j*64 + lane]: conflict-free), unit costs
+constexpr int ED_MAX = 128;
+__global__ __launch_bounds__(64) void edit_distance_kernel(const int* __restrict__ pred, int ldp, const int* __restrict__ pred_len,
+                                                           const int* __restrict__ gt, const long long* __restrict__ gt_off,
+                                                           const int* __restrict__ gt_len, int N, int* __restrict__ out) {
+  __shared__ int row[(ED_MAX + 1) * 64];
+  const int lane = threadIdx.x;
+  const int n = blockIdx.x * 64 + lane;
+  if (n >= N) return;
+  const int lp = min(pred_len[n], ED_MAX), lg = gt_len[n];
+  const int* p = pred + (size_t)n * ldp;
+  const int* g = gt + gt_off[n];
+  for (int j = 0; j <= lp; ++j) row[j * 64 + lane] = j;
+  for (int i = 1; i <= lg; ++i) {
+    const int gc = g[i - 1];
+    int diag = row[lane];  // D[i-1][0]
+    row[lane] = i;
+    int left = i;
+    for (int j = 1; j <= lp; ++j) {
+      const int up = row[j * 64 + lane];
+      const int v = min(min(up + 1, left + 1), diag + (p[j - 1] != gc));
+      row[j * 64 + lane] = v;
+      diag = up;
+      left = v;
+    }
+  }
+  out[n] = row[lp * 64 + lane];
+}
+
 int grid_for(long long n, int cap = 4096) {
   long long g = (n + 255) / 256;
   if (g > cap) g = cap;
@@ -276,6 +306,16 @@ extern "C" int qea_greedy_decode(const float* scores, int32_t ld_t, int32_t ld_n
                                  int32_t* tokens, int32_t* lengths, void* stream) {
   QEA_REQUIRE(scores && tokens && lengths && T > 0 && N > 0 && C > 0, "qea_greedy_decode: bad arguments");
   hipLaunchKernelGGL(greedy_decode_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, scores, ld_t, ld_n, T, N, C, blank, tokens, lengths);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_edit_distance(const int32_t* pred_tokens, int32_t ldp, const int32_t* pred_len, const int32_t* gt_tokens,
+                                 const int64_t* gt_offsets, const int32_t* gt_len, int32_t N, int32_t* out, void* stream) {
+  QEA_REQUIRE(pred_tokens && pred_len && gt_tokens && gt_offsets && gt_len && out && N > 0 && ldp > 0 && ldp <= ED_MAX,
+              "qea_edit_distance: bad arguments (prediction length <= %d)", ED_MAX);
+  hipLaunchKernelGGL(edit_distance_kernel, dim3(qea_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, pred_tokens, ldp, pred_len, gt_tokens,
+                     (const long long*)gt_offsets, gt_len, N, out);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

@@ -233,3 +233,8 @@ def prof_read_launches(klass, capacity=4096):
     _lib.check(_lib.lib().qea_prof_read_launches(klass, ms.ctypes.data, fl.ctypes.data, capacity, C.byref(n)), "qea_prof_read_launches")
     k = min(n.value, capacity)
     return ms[:k], fl[:k]
+
+
+def edit_distance(pred_tokens, ldp, pred_len, gt_tokens, gt_offsets, gt_len, N, out):
+    _lib.check(_lib.lib().qea_edit_distance(_ptr(pred_tokens), ldp, _ptr(pred_len), _ptr(gt_tokens), _ptr(gt_offsets), _ptr(gt_len), N,
+                                            _ptr(out), _stream()), "qea_edit_distance")

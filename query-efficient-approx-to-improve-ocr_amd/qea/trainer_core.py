@@ -210,9 +210,14 @@ class TrainerCore:
             save_all_jsons(self, epoch)
 
     def _update_cers(self, scores, labels, names):
-        """decode -> per-sample CER -> sampler.update_cer (train_nn_patch.py:330-342)."""
-        model_gen_labels = pred_to_string(scores, labels, self.index_to_char)
-        if self.selection_method and len(names):
-            batch_cers = [compare_labels([p], [l])[1] for p, l in zip(model_gen_labels, labels)]
-            self.sampler.update_cer(batch_cers, names)
-        return model_gen_labels
+        """decode -> per-sample CER -> sampler.update_cer (train_nn_patch.py:330-342).  On the GPU the decode and
+        the edit distances stay on the device (no [T,B,C] copy, no Python loop with an .item() per (b,t))."""
+        if not (self.selection_method and len(names)):
+            return
+        if scores.is_cuda and scores.shape[0] <= 128:
+            from utils import batch_cers
+            cers = batch_cers(scores, labels, self.char_to_index)
+        else:
+            preds = pred_to_string(scores, labels, self.index_to_char)
+            cers = [compare_labels([p], [l])[1] for p, l in zip(preds, labels)]
+        self.sampler.update_cer(cers, names)

@@ -79,6 +79,31 @@ def compare_labels(preds, labels):
     return correct, total_cer
 
 
+def batch_cers(scores, labels, char_to_index, blank=0):
+    """Per-sample CER of the greedy decode of `scores` [T,B,C] against `labels`, entirely on the GPU up to
+    the final division: decode kernel -> edit-distance kernel -> one [B] int32 copy to the host.  Equals
+    [compare_labels([pred_i], [label_i])[1] for i] of the reference loop (train_nn_patch.py:336-342)."""
+    from qea import ops
+    T, B, C = scores.shape
+    s = scores.detach()
+    if s.stride(2) != 1:
+        s = s.contiguous()
+    dev = s.device
+    tokens = torch.empty(B, T, dtype=torch.int32, device=dev)
+    plen = torch.empty(B, dtype=torch.int32, device=dev)
+    ops.greedy_decode(s, s.stride(0), s.stride(1), T, B, C, blank, tokens, plen)
+    glen = torch.tensor([len(l) for l in labels], dtype=torch.int32)
+    goff = torch.zeros(B, dtype=torch.int64)
+    if B > 1:
+        goff[1:] = torch.cumsum(glen.to(torch.int64), 0)[:-1]
+    flat = [char_to_index[c] for c in "".join(labels)] or [0]
+    gt = torch.tensor(flat, dtype=torch.int32)
+    dist = torch.empty(B, dtype=torch.int32, device=dev)
+    ops.edit_distance(tokens, T, plen, gt.to(dev), goff.to(dev), glen.to(dev), B, dist)
+    d = dist.cpu().tolist()
+    return [d[i] / max(1, len(labels[i])) for i in range(B)]
+
+
 def set_bn_eval(module):
     if isinstance(module, torch.nn.modules.batchnorm._BatchNorm):
         module.eval()

@@ -456,3 +456,20 @@ def test_greedy_decode_matches_reference_strings():
     tk, ln = tokens.cpu().tolist(), lengths.cpu().tolist()
     got = ["".join(H.I2C[i] for i in tk[n][:ln[n]]) for n in range(N)]
     assert got == [str(s) for s in fx["dec|strings"]]
+
+
+def test_device_cer_matches_host_reference_loop():
+    """decode + edit distance on the device == pred_to_string + compare_labels per sample (bit-exact ints)."""
+    import utils
+    from oracle import path_oracle as po
+    g = torch.Generator().manual_seed(23)
+    T, B, Cc = 31, 200, 95
+    scores = torch.randn(T, B, Cc, generator=g)
+    scores[:, :, 0] += 1.5
+    labels = H.synth_labels(B, 9, 0, 20)
+    labels[3] = ""
+    labels[7] = "x" * 100
+    cers = utils.batch_cers(scores.cuda(), labels, H.C2I)
+    preds = po.greedy_decode(scores.numpy(), H.I2C)
+    ref = [po.compare_labels([p], [l])[1] for p, l in zip(preds, labels)]
+    assert cers == ref
