@@ -1,0 +1,1 @@
+"""Datasets: synthetic generators and the reference on-disk formats (ImgDataset, PatchDataset)."""

