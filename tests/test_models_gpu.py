@@ -218,3 +218,58 @@ def test_checkpoint_roundtrip(tmp_path):
         y1 = net2(x)
     assert torch.equal(y0, y1)
     assert list(net2.state_dict().keys()) == list(mo.unet_state_shapes().keys())
+
+
+@pytest.mark.parametrize("W", [64, 256])
+def test_crnn_other_widths_vs_oracle(W):
+    """The kernels are width-agnostic (W % 16 == 0, T = W/4 - 1): BASELINE configs[4] as reinterpreted in SURVEY F8."""
+    from models.model_crnn import CRNN
+    from oracle import model_oracle as mo
+    from oracle import step_oracle as so
+    from qea.loss import CTCLoss
+    B = 3
+    x = torch.rand(B, 1, 32, W, generator=torch.Generator().manual_seed(W))
+    labels = H.synth_labels(B, W, 1, 8)
+    sc = mo.seeded_state(mo.crnn_state_shapes(), 5)
+    P, Bf = mo.split_state({k: (v.double() if v.is_floating_point() else v) for k, v in sc.items()})
+    xr = x.double().requires_grad_()
+    lp_r = mo.crnn_forward(P, Bf, xr, bn_training=False)
+    y, ysz = H.encode(labels)
+    T = W // 4 - 1
+    assert lp_r.shape[0] == T
+    loss_r = torch.nn.functional.ctc_loss(lp_r, y, torch.full((B,), T, dtype=torch.int), ysz)
+    loss_r.backward()
+    net = CRNN(95, False)
+    net.load_state_dict(sc)
+    net = net.cuda().train()
+    net.register_backward_hook(net.backward_hook)
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    xg = x.cuda().requires_grad_()
+    lp = net(xg)
+    assert lp.shape == (T, B, 95)
+    loss = CTCLoss()(lp, y, torch.full((B,), T, dtype=torch.int), ysz)
+    loss.backward()
+    assert (lp.detach().cpu().double() - lp_r.detach()).abs().max().item() < 2e-4
+    assert abs(loss.item() - loss_r.item()) < 1e-4 * abs(loss_r.item())
+    assert _rel(xg.grad, xr.grad) < 1e-3
+    for name, p in net.named_parameters():
+        err, _ = H.robust_rel_err(p.grad, P[name].grad)
+        assert err < 2e-3, (name, err)
+
+
+def test_unet_other_size_vs_oracle():
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    x = torch.rand(2, 1, 48, 160, generator=torch.Generator().manual_seed(4))
+    su = mo.seeded_state(mo.unet_state_shapes(), 9)
+    P, Bf = mo.split_state({k: (v.double() if v.is_floating_point() else v) for k, v in su.items()})
+    with torch.no_grad():
+        y_r = mo.unet_forward(P, Bf, x.double(), training=False)
+    net = UNet()
+    net.load_state_dict(su)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(x.cuda())
+    assert y.shape == (2, 1, 48, 160) and (y.cpu().double() - y_r).abs().max().item() < 2e-5
