@@ -260,7 +260,7 @@ def main():
                                                       "convT, LSTM/linear GEMMs)",
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_pmc_traffic.json",
-                         "algorithmic_bytes_per_launch": None, "launches_per_step": ig["launches"] / args.steps,
+                         "algorithmic_bytes_per_launch": ig["bytes"] / max(1, ig["launches"]), "launches_per_step": ig["launches"] / args.steps,
                          "ms_per_step_in_kernel": ig["ms"] / args.steps},
             "kernels": {
                 "conv_wgrad": {"tflops": wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0, "ms_per_step": wg["ms"] / args.steps,
