@@ -175,10 +175,10 @@ def main():
         with torch.no_grad():
             preds_all = prep(x)
         preds, _, _ = sampler.query(preds_all, names, kA, names)
-        lossA = None
-        for _ in range(inner_limit):
-            noisy, _ = noiser.batch(preds, replicas=1)
-            lossA = ctc(crnn(noisy), yA, insA, lensA)
+        # all replicas in ONE Philox launch and ONE CRNN pass with per-replica-group BatchNorm
+        noisy, _ = noiser.batch(preds, replicas=inner_limit)
+        lpA = crnn(noisy, replica_groups=inner_limit)
+        lossA = ctc(lpA[:, (inner_limit - 1) * kA:, :], yA, insA, lensA)
         lossA.backward()                             # area flow: last replica only
         if use_dist:
             dist.all_reduce(fc.grad)
@@ -236,7 +236,8 @@ def main():
             dist.all_reduce(tf, op=dist.ReduceOp.MAX)
         full = {"value": B * world * args.steps / tf.item(), "unit": "patch-images/s", "ms_per_step": tf.item() / args.steps * 1e3,
                 "phase_a": {"selection": "topKCER", "minibatch_subset_prop": 0.95, "k_per_gpu": kA, "inner_limit": 4,
-                            "backward": "last replica (train_nn_area.py:269-271)", "ocr": "fixed labels (black box excluded)"}}
+                            "backward": "last replica (train_nn_area.py:269-271)", "replicas": "fused in the batch dim, per-group BN",
+                            "ocr": "fixed labels (black box excluded)"}}
     tmax = torch.tensor([dt], device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

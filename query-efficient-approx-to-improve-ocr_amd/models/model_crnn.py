@@ -74,7 +74,10 @@ class CRNN(nn.Module):
             raise QeaError("CRNN: batchnorm1/batchnorm2 must be in the same mode")
         return modes.pop()
 
-    def forward(self, x):
+    def forward(self, x, replica_groups=1):
+        """x [B,1,32,W] -> log-probs [T,B,vocab].  replica_groups = R (new, additive): x holds R jitter replicas
+        of the same strips stacked replica-major; batch-stat BatchNorm runs per replica group, so one call equals R
+        sequential calls of the reference on the R replicas (see CRNNEngine.forward)."""
         _require_cuda(x, "CRNN")
         eng = self._engine()
         ensure_flat(self)
@@ -84,7 +87,8 @@ class CRNN(nn.Module):
             self.__dict__["_qea_anchor"] = anchor
         wants = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         skip = self.__dict__.get("_qea_skip_param_grads", False)
-        return CRNNFn.apply(x, anchor if wants else None, eng, self._bn_mode(), bool(self.__dict__.get("_qea_nan_scrub", False)), not skip)
+        return CRNNFn.apply(x, anchor if wants else None, eng, self._bn_mode(), bool(self.__dict__.get("_qea_nan_scrub", False)), not skip,
+                            int(replica_groups))
 
     def map_to_sequence(self, map):
         batch, channel, height, width = map.size()

@@ -30,7 +30,11 @@ class CRNNEngine:
         self.cp = "convo.module." if any(n.startswith("convo.module.") for n, _ in module.named_parameters()) else "convo."
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, bn_training, need_grad):
+    def forward(self, x, bn_training, need_grad, groups=1):
+        """groups > 1: the batch is `groups` jitter replicas of the same strips stacked along N (replica-major).
+        Batch-statistic BatchNorm is then evaluated PER REPLICA GROUP and the running statistics are updated once
+        per group in order, which is exactly what `groups` sequential forward passes of the reference do
+        (sharing the statistics across replicas changes the gradients by 4e-2)."""
         fs = ensure_flat(self.m)
         P = dict(self.m.named_parameters())
         Bf = dict(self.m.named_buffers())
@@ -39,7 +43,9 @@ class CRNNEngine:
         if H != 32 or W % 4:
             raise ValueError(f"CRNN input must be [B,1,32,W] with W % 4 == 0, got {H}x{W}")
         c = self.cp
-        ctx = {"x": x, "B": B, "H": H, "W": W, "bn_training": bn_training} if need_grad else None
+        if B % groups:
+            raise ValueError(f"batch {B} is not a multiple of groups={groups}")
+        ctx = {"x": x, "B": B, "H": H, "W": W, "bn_training": bn_training, "groups": groups} if need_grad else None
 
         # conv1 (C_in = 1) + ReLU, pool 2x2
         a1 = torch.empty(B * H * W, 64, device=dev)
@@ -70,22 +76,26 @@ class CRNNEngine:
             y = torch.empty(M, 512, device=dev)
             ops.conv_igemm(cur, P[c + name + ".weight"], y, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=512, KH=3, KW=3, pad=(1, 1),
                            ldx=cin, ldy=512, bias=P[c + name + ".bias"])
-            coef = torch.empty(4, 512, device=dev)
-            stat64 = None
-            if bn_training:
-                stat64 = torch.empty(2, 512, device=dev, dtype=torch.float64) if need_grad else None
-                ops.bn_train_stats(y, 512, M, 512, P[c + bn + ".weight"], P[c + bn + ".bias"], BN_EPS, BN_MOMENTUM,
-                                   Bf[c + bn + ".running_mean"], Bf[c + bn + ".running_var"], coef[0], coef[1], coef[2], coef[3], stat64)
-            else:
-                ops.bn_eval_coeff(512, P[c + bn + ".weight"], P[c + bn + ".bias"], Bf[c + bn + ".running_mean"],
-                                  Bf[c + bn + ".running_var"], BN_EPS, None, coef[0], coef[1], coef[2], coef[3])
+            G = groups if bn_training else 1
+            Mg = M // G
+            coef = torch.empty(G, 4, 512, device=dev)
+            stat64 = torch.empty(G, 2, 512, device=dev, dtype=torch.float64) if (bn_training and need_grad) else None
             a = torch.empty(M, 512, device=dev)
-            ops.bn_apply(y, 512, a, 512, M, 512, coef[2], coef[3], relu=True)
+            for gi in range(G):
+                yg, ag = y[gi * Mg:(gi + 1) * Mg], a[gi * Mg:(gi + 1) * Mg]
+                if bn_training:
+                    ops.bn_train_stats(yg, 512, Mg, 512, P[c + bn + ".weight"], P[c + bn + ".bias"], BN_EPS, BN_MOMENTUM,
+                                       Bf[c + bn + ".running_mean"], Bf[c + bn + ".running_var"], coef[gi, 0], coef[gi, 1], coef[gi, 2],
+                                       coef[gi, 3], stat64[gi] if stat64 is not None else None)
+                else:
+                    ops.bn_eval_coeff(512, P[c + bn + ".weight"], P[c + bn + ".bias"], Bf[c + bn + ".running_mean"],
+                                      Bf[c + bn + ".running_var"], BN_EPS, None, coef[gi, 0], coef[gi, 1], coef[gi, 2], coef[gi, 3])
+                ops.bn_apply(yg, 512, ag, 512, Mg, 512, coef[gi, 2], coef[gi, 3], relu=True)
             acts["y" + name[-1]], acts["coef" + name[-1]], acts["a" + name[-1]], acts["st" + name[-1]] = y, coef, a, stat64
             dims[name] = (h, w)
             cur = a
         if bn_training:
-            fs.ibuf.add_(1)
+            fs.ibuf.add_(groups)
         p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
         ops.maxpool_fwd(cur, 512, p6, 512, B, h, w, 512, 2, 1)
         acts["p6"] = p6
@@ -218,9 +228,15 @@ class CRNNEngine:
             k = name[-1]
             coef = acts["coef" + k]
             dy_ = torch.empty(M, 512, device=dev)
-            ops.bn_bwd(da, 512, acts["a" + k], 512, acts["y" + k], 512, M, 512, P[c + bn + ".weight"], coef[0], coef[1], bn_training,
-                       G[c + bn + ".weight"] if param_grads else None, G[c + bn + ".bias"] if param_grads else None, dy_, 512,
-                       accumulate=True, stat64=acts["st" + k])
+            NG = coef.shape[0]
+            Mg = M // NG
+            for gi in range(NG):
+                sl = slice(gi * Mg, (gi + 1) * Mg)
+                st = acts["st" + k]
+                ops.bn_bwd(da[sl], 512, acts["a" + k][sl], 512, acts["y" + k][sl], 512, Mg, 512, P[c + bn + ".weight"], coef[gi, 0],
+                           coef[gi, 1], bn_training, G[c + bn + ".weight"] if param_grads else None,
+                           G[c + bn + ".bias"] if param_grads else None, dy_[sl], 512, accumulate=True,
+                           stat64=st[gi] if st is not None else None)
             if param_grads:
                 ops.colsum(dy_, 512, M, 512, G[c + name + ".bias"], accumulate=True)
                 ops.conv_wgrad(dy_, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=512, Cc=cin, KH=3, KW=3,

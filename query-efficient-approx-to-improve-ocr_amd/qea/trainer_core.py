@@ -159,6 +159,35 @@ class TrainerCore:
         res = [noiser(img) for img in imgs]
         return torch.stack([r[0] if isinstance(r, tuple) else r for r in res])
 
+    def _replica_losses(self, imgs, noiser, R):
+        """The R jittered CRNN passes of Phase A (train_nn_patch.py:288-294 repeated R times).
+        HIP path: ONE Philox launch makes all R*k noisy strips, ONE black-box call labels them, ONE CRNN pass with
+        per-replica-group BatchNorm scores them; the per-replica CTC losses come back as a list (same values,
+        same running-stat updates as R sequential passes — tests/test_models_gpu.py::test_replica_groups...).
+        Injected CPU backend: the reference's sequential loop."""
+        k = imgs.shape[0]
+        if R <= 0:
+            return [], 0
+        if self.backend.gpu_jitter and imgs.is_cuda and R > 1:
+            noisy, _ = noiser.batch(imgs, replicas=R)
+            ocr_labels = self.ocr.get_labels(noisy.cpu())
+            scores = self.crnn_model(noisy, replica_groups=R)
+            out_size = torch.tensor([scores.shape[0]] * k, dtype=torch.int)
+            losses = []
+            for r in range(R):
+                labels = ocr_labels[r * k:(r + 1) * k]
+                y = torch.tensor([self.char_to_index[c] for c in "".join(labels)], dtype=torch.int)
+                y_size = torch.tensor([len(l) for l in labels], dtype=torch.int)
+                losses.append(self.primary_loss_fn(scores[:, r * k:(r + 1) * k, :], y, out_size, y_size))
+            return losses, R * k
+        losses = []
+        for _ in range(R):
+            noisy = self._jitter(imgs, noiser)
+            ocr_labels = self.ocr.get_labels(noisy.cpu())
+            scores, y, pred_size, y_size = self._call_model(noisy, ocr_labels)
+            losses.append(self.primary_loss_fn(scores, y, pred_size, y_size))
+        return losses, R * k
+
     def _num_bb_samples(self, n):
         return max(1, math.ceil(n * (1 - self.train_batch_prop)))
 

@@ -89,21 +89,21 @@ class TrainNNPrep(TrainerCore):
                 else:
                     img_preds, img_preds_names = img_preds_all.detach(), names
                 loss = None
-                for i in range(self.inner_limit):
-                    if i == 0 and self.inner_limit_skip:
-                        ocr_labels = self.ocr.get_labels(img_preds.cpu())
-                        loss_weights = self.loss_wghts_gnrtr.gen_weights(self.tracked_labels, img_preds_names)
-                        add_labels_to_history(self, img_preds_names, ocr_labels)
-                        target_batches = generate_ctc_target_batches(self, img_preds_names)
-                        scores, pred_size = call_crnn(self, img_preds)
-                        loss = weighted_ctc_loss(self, scores, pred_size, target_batches, loss_weights)
-                    else:
-                        noisy = self._jitter(img_preds, noiser)
-                        ocr_labels = self.ocr.get_labels(noisy.cpu())
-                        scores, y, pred_size, y_size = self._call_model(noisy, ocr_labels)
-                        loss = self.primary_loss_fn(scores, y, pred_size, y_size)
+                n_skip = 1 if (self.inner_limit_skip and self.inner_limit > 0) else 0
+                if n_skip:                                       # iteration 0 without noise: label tracking (:247-259)
+                    ocr_labels = self.ocr.get_labels(img_preds.cpu())
+                    loss_weights = self.loss_wghts_gnrtr.gen_weights(self.tracked_labels, img_preds_names)
+                    add_labels_to_history(self, img_preds_names, ocr_labels)
+                    target_batches = generate_ctc_target_batches(self, img_preds_names)
+                    scores, pred_size = call_crnn(self, img_preds)
+                    loss = weighted_ctc_loss(self, scores, pred_size, target_batches, loss_weights)
                     total_bb_calls += len(ocr_labels)
                     epoch_bb_calls += len(ocr_labels)
+                rep_losses, calls = self._replica_losses(img_preds, noiser, self.inner_limit - n_skip)
+                total_bb_calls += calls
+                epoch_bb_calls += calls
+                if rep_losses:
+                    loss = rep_losses[-1]
                 if self.inner_limit:
                     CRNN_training_loss = loss.item() / max(1, self.inner_limit)
                     loss.backward()                              # the last replica only, as the reference (:269-271)

@@ -105,23 +105,28 @@ class TrainNNPrep(TrainerCore):
                         crops, crop_names = crops_all, strip_names
                     crops = crops.detach()
                     approx_loss = 0.0
-                    for j in range(self.inner_limit):
-                        if j == 0 and self.inner_limit_skip:
-                            ocr_labels = self.ocr.get_labels(crops.cpu())
-                            loss_weights = self.loss_wghts_gnrtr.gen_weights(self.tracked_labels, crop_names)
-                            add_labels_to_history(self, crop_names, ocr_labels)
-                            target_batches = generate_ctc_target_batches(self, crop_names)
-                            scores, pred_size = call_crnn(self, crops)
-                            loss = weighted_ctc_loss(self, scores, pred_size, target_batches, loss_weights)
-                        else:
-                            noisy = self._jitter(crops, noiser)
-                            ocr_labels = self.ocr.get_labels(noisy.cpu())
-                            scores, y, pred_size, y_size = self._call_model(noisy, ocr_labels)
-                            loss = self.primary_loss_fn(scores, y, pred_size, y_size)
+                    n_skip = 1 if (self.inner_limit_skip and self.inner_limit > 0) else 0
+                    if n_skip:                                   # iteration 0 without noise: label tracking (:280-287)
+                        ocr_labels = self.ocr.get_labels(crops.cpu())
+                        loss_weights = self.loss_wghts_gnrtr.gen_weights(self.tracked_labels, crop_names)
+                        add_labels_to_history(self, crop_names, ocr_labels)
+                        target_batches = generate_ctc_target_batches(self, crop_names)
+                        scores, pred_size = call_crnn(self, crops)
+                        loss = weighted_ctc_loss(self, scores, pred_size, target_batches, loss_weights)
+                        approx_loss += loss.item()
+                        loss.backward()
                         total_bb_calls += crops.shape[0]
                         epoch_bb_calls += crops.shape[0]
-                        approx_loss += loss.item()
-                        loss.backward()                          # every replica: gradients accumulate (:301-303)
+                    rep_losses, calls = self._replica_losses(crops, noiser, self.inner_limit - n_skip)
+                    total_bb_calls += calls
+                    epoch_bb_calls += calls
+                    if rep_losses:
+                        # every replica is back-propagated and the gradients accumulate (:301-303): backward of the sum
+                        total = rep_losses[0]
+                        for l in rep_losses[1:]:
+                            total = total + l
+                        approx_loss += total.item()
+                        total.backward()
                     CRNN_training_loss += approx_loss / max(1, self.inner_limit)
                 if self.inner_limit:
                     self._step_crnn()

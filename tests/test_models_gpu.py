@@ -273,3 +273,44 @@ def test_unet_other_size_vs_oracle():
     with torch.no_grad():
         y = net(x.cuda())
     assert y.shape == (2, 1, 48, 160) and (y.cpu().double() - y_r).abs().max().item() < 2e-5
+
+
+def test_replica_groups_equal_sequential_passes():
+    """R jitter replicas fused into the batch dimension with per-replica-group BatchNorm == R sequential
+    CRNN passes of the reference loop: same log-probs, same gradients (sum of the replica losses), same
+    running statistics."""
+    from models.model_crnn import CRNN
+    from oracle import model_oracle as mo
+    from qea.loss import CTCLoss
+    R, k = 3, 4
+    sc = mo.seeded_state(mo.crnn_state_shapes(), 7)
+    x = torch.stack([H.synth_images(k, 50 + r) for r in range(R)]).reshape(R * k, 1, 32, 128).cuda()
+    labels = [H.synth_labels(k, 60 + r, 1, 8) for r in range(R)]
+    ins = torch.full((k,), 31, dtype=torch.int)
+
+    def make():
+        net = CRNN(95, False)
+        net.load_state_dict(sc)
+        net = net.cuda().train()
+        net.register_backward_hook(net.backward_hook)
+        net.zero_grad()
+        return net
+    seq = make()
+    lps = []
+    for r in range(R):
+        lp = seq(x[r * k:(r + 1) * k])
+        y, ysz = H.encode(labels[r])
+        CTCLoss()(lp, y, ins, ysz).backward()
+        lps.append(lp.detach())
+    fused = make()
+    lp_all = fused(x, replica_groups=R)
+    total = 0
+    for r in range(R):
+        y, ysz = H.encode(labels[r])
+        total = total + CTCLoss()(lp_all[:, r * k:(r + 1) * k, :], y, ins, ysz)
+    total.backward()
+    assert torch.equal(lp_all.detach(), torch.cat(lps, dim=1))
+    for (n, a), (_, b) in zip(fused.named_parameters(), seq.named_parameters()):
+        assert _rel(a.grad, b.grad) < 2e-5, n
+    for (n, a), (_, b) in zip(fused.named_buffers(), seq.named_buffers()):
+        assert torch.equal(a, b), n
