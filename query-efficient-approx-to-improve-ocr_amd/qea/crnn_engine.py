@@ -151,6 +151,10 @@ class CRNNEngine:
         vp, V = self.vpad, self.vocab
         c = self.cp
         TB = T * B
+        side = self.__dict__.get("_side")
+        if side is None or side.side is not None and side.side.device != dev:
+            side = ops.SideStream(dev)
+            self._side = side
 
         g = dlp.contiguous().view(TB, V)
         dlogits = torch.empty(TB, vp, device=dev)
@@ -159,12 +163,14 @@ class CRNNEngine:
         # Linear
         y1 = ctx["lstm"][1]["y"]
         if param_grads:
-            dwl = torch.empty(vp, 512, device=dev)
-            ops.conv_wgrad(dlogits, y1, dwl, B=1, PH=1, PW=TB, QH=1, QW=TB, R=vp, Cc=512, KH=1, KW=1, ldp=vp, ldq=512)
-            G["linear.weight"].add_(dwl[:V])
-            dbl = torch.empty(vp, device=dev)
-            ops.colsum(dlogits, vp, TB, vp, dbl)
-            G["linear.bias"].add_(dbl[:V])
+            def linear_grads():
+                dwl = torch.empty(vp, 512, device=dev)
+                ops.conv_wgrad(dlogits, y1, dwl, B=1, PH=1, PW=TB, QH=1, QW=TB, R=vp, Cc=512, KH=1, KW=1, ldp=vp, ldq=512)
+                G["linear.weight"].add_(dwl[:V])
+                dbl = torch.empty(vp, device=dev)
+                ops.colsum(dlogits, vp, TB, vp, dbl)
+                G["linear.bias"].add_(dbl[:V])
+            side.run(linear_grads, dlogits)
         wpad = torch.zeros(vp, 512, device=dev)
         wpad[:V].copy_(P["linear.weight"])
         wlT = torch.empty(512, vp, device=dev)
@@ -180,20 +186,22 @@ class CRNNEngine:
             dc = torch.empty(B, 2 * HID, device=dev)
             ops.lstm_layer_bwd(gates, cst, dy, s["pb"], dc, T, B)          # gates now hold dgates
             if param_grads:
-                for d, suf in enumerate(("", "_reverse")):
-                    dg = gates[:, :, d * 4 * HID:]
-                    ops.conv_wgrad(dg, xin, G[f"lstm.weight_ih_l{layer}{suf}"], B=1, PH=1, PW=TB, QH=1, QW=TB, R=4 * HID, Cc=512,
-                                   KH=1, KW=1, ldp=8 * HID, ldq=512, accumulate=True)
-                    ops.colsum(dg, 8 * HID, TB, 4 * HID, G[f"lstm.bias_ih_l{layer}{suf}"], accumulate=True)
-                    ops.colsum(dg, 8 * HID, TB, 4 * HID, G[f"lstm.bias_hh_l{layer}{suf}"], accumulate=True)
-                    if T > 1:
-                        n = (T - 1) * B
-                        if d == 0:
-                            pg, qh = gates[1:, :, :4 * HID], yl[:T - 1, :, :HID]
-                        else:
-                            pg, qh = gates[:T - 1, :, 4 * HID:], yl[1:, :, HID:]
-                        ops.conv_wgrad(pg, qh, G[f"lstm.weight_hh_l{layer}{suf}"], B=1, PH=1, PW=n, QH=1, QW=n, R=4 * HID, Cc=HID,
-                                       KH=1, KW=1, ldp=8 * HID, ldq=2 * HID, accumulate=True)
+                def lstm_grads(layer=layer, gates=gates, xin=xin, yl=yl):
+                    for d, suf in enumerate(("", "_reverse")):
+                        dg = gates[:, :, d * 4 * HID:]
+                        ops.conv_wgrad(dg, xin, G[f"lstm.weight_ih_l{layer}{suf}"], B=1, PH=1, PW=TB, QH=1, QW=TB, R=4 * HID, Cc=512,
+                                       KH=1, KW=1, ldp=8 * HID, ldq=512, accumulate=True)
+                        ops.colsum(dg, 8 * HID, TB, 4 * HID, G[f"lstm.bias_ih_l{layer}{suf}"], accumulate=True)
+                        ops.colsum(dg, 8 * HID, TB, 4 * HID, G[f"lstm.bias_hh_l{layer}{suf}"], accumulate=True)
+                        if T > 1:
+                            n = (T - 1) * B
+                            if d == 0:
+                                pg, qh = gates[1:, :, :4 * HID], yl[:T - 1, :, :HID]
+                            else:
+                                pg, qh = gates[:T - 1, :, 4 * HID:], yl[1:, :, HID:]
+                            ops.conv_wgrad(pg, qh, G[f"lstm.weight_hh_l{layer}{suf}"], B=1, PH=1, PW=n, QH=1, QW=n, R=4 * HID, Cc=HID,
+                                           KH=1, KW=1, ldp=8 * HID, ldq=2 * HID, accumulate=True)
+                side.run(lstm_grads)
             wcat = torch.cat((P[f"lstm.weight_ih_l{layer}"], P[f"lstm.weight_ih_l{layer}_reverse"]), 0)   # [2048][512]
             wT = torch.empty(512, 8 * HID, device=dev)
             ops.transpose2d(wcat, wT, 8 * HID, 512)
@@ -211,9 +219,11 @@ class CRNNEngine:
         h6, w6 = ctx["h6"], ctx["w6"]
         p6 = acts["p6"]
         if param_grads:
-            ops.colsum(dseq_bt, 512, B * T, 512, G[c + "conv7.bias"], accumulate=True)
-            ops.conv_wgrad(dseq_bt, p6, G[c + "conv7.weight"], B=B, PH=1, PW=T, QH=h6, QW=w6, R=512, Cc=512, KH=2, KW=2, ldp=512, ldq=512,
-                           accumulate=True)
+            def conv7_grads():
+                ops.colsum(dseq_bt, 512, B * T, 512, G[c + "conv7.bias"], accumulate=True)
+                ops.conv_wgrad(dseq_bt, p6, G[c + "conv7.weight"], B=B, PH=1, PW=T, QH=h6, QW=w6, R=512, Cc=512, KH=2, KW=2, ldp=512,
+                               ldq=512, accumulate=True)
+            side.run(conv7_grads, dseq_bt)
         w7t = torch.empty(512, 2, 2, 512, device=dev)
         ops.filter_flip_transpose(P[c + "conv7.weight"], w7t, 512, 512, 2, 2)
         dp6 = torch.empty(B * h6 * w6, 512, device=dev)
@@ -238,9 +248,11 @@ class CRNNEngine:
                            G[c + bn + ".bias"] if param_grads else None, dy_[sl], 512, accumulate=True,
                            stat64=st[gi] if st is not None else None)
             if param_grads:
-                ops.colsum(dy_, 512, M, 512, G[c + name + ".bias"], accumulate=True)
-                ops.conv_wgrad(dy_, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=512, Cc=cin, KH=3, KW=3,
-                               pad=(1, 1), ldp=512, ldq=cin, accumulate=True)
+                def bn_conv_grads(dy_=dy_, name=name, src=src, cin=cin, M=M):
+                    ops.colsum(dy_, 512, M, 512, G[c + name + ".bias"], accumulate=True)
+                    ops.conv_wgrad(dy_, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=512, Cc=cin, KH=3, KW=3,
+                                   pad=(1, 1), ldp=512, ldq=cin, accumulate=True)
+                side.run(bn_conv_grads, dy_)
             wt = torch.empty(cin, 3, 3, 512, device=dev)
             ops.filter_flip_transpose(P[c + name + ".weight"], wt, 512, cin, 3, 3)
             da = torch.empty(M, cin, device=dev)
@@ -259,9 +271,11 @@ class CRNNEngine:
                 dyc = dcur                                  # already masked by the producer's epilogue
             src = {"conv4": "a3", "conv3": "p2", "conv2": "p1"}[name]
             if param_grads:
-                ops.colsum(dyc, cout, M, cout, G[c + name + ".bias"], accumulate=True)
-                ops.conv_wgrad(dyc, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
-                               pad=(1, 1), ldp=cout, ldq=cin, accumulate=True)
+                def conv_grads(dyc=dyc, name=name, src=src, cin=cin, cout=cout, M=M, h=h, w=w):
+                    ops.colsum(dyc, cout, M, cout, G[c + name + ".bias"], accumulate=True)
+                    ops.conv_wgrad(dyc, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
+                                   pad=(1, 1), ldp=cout, ldq=cin, accumulate=True)
+                side.run(conv_grads, dyc)
             wt = torch.empty(cin, 3, 3, cout, device=dev)
             ops.filter_flip_transpose(P[c + name + ".weight"], wt, cout, cin, 3, 3)
             dnext = torch.empty(M, cin, device=dev)
@@ -274,9 +288,11 @@ class CRNNEngine:
         dy1 = torch.empty(B * H * W, 64, device=dev)
         ops.maxpool_bwd(acts["a1"], 64, dcur, 64, dy1, 64, B, H, W, 64, 2, 2, relu_mask=True)
         if param_grads:
-            ops.conv_c1_wgrad(ctx["x"], dy1, 64, G[c + "conv1.weight"], G[c + "conv1.bias"], B, H, W, 64, accumulate=True)
-        if not need_dx:
-            return None
-        dx = torch.empty(B, 1, H, W, device=dev)
-        ops.conv_c1_dgrad(dy1, 64, P[c + "conv1.weight"], dx, B, H, W, 64)
+            side.run(lambda: ops.conv_c1_wgrad(ctx["x"], dy1, 64, G[c + "conv1.weight"], G[c + "conv1.bias"], B, H, W, 64, accumulate=True),
+                     dy1)
+        dx = None
+        if need_dx:
+            dx = torch.empty(B, 1, H, W, device=dev)
+            ops.conv_c1_dgrad(dy1, 64, P[c + "conv1.weight"], dx, B, H, W, 64)
+        side.join()
         return dx

@@ -30,8 +30,8 @@ def _ptr(t):
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device (caller-owned workspace of the C ABI)."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer per (device, stream): kernels on different streams never share one."""
+    key = (device.type, device.index, _stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -62,6 +62,58 @@ def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride
         d.workspace = ws.data_ptr()
         d.workspace_bytes = ws.numel()
     _lib.check(L.qea_conv_wgrad(C.byref(d), _stream()), "qea_conv_wgrad")
+
+
+_overlap = {"on": None}
+
+
+def set_overlap(on):
+    """Switch the wgrad side stream on/off at run time (bench.py times with it on and measures per-kernel
+    durations with it off, because a launch's event-to-event time otherwise includes a co-running kernel)."""
+    _overlap["on"] = bool(on)
+
+
+def overlap_enabled():
+    if _overlap["on"] is None:
+        import os
+        _overlap["on"] = os.environ.get("QEA_OVERLAP", "1") != "0"
+    return _overlap["on"]
+
+
+class SideStream:
+    """Runs weight-gradient work beside the main backward chain.  The dgrad -> BN-backward -> dgrad chain is a
+    strict dependency chain with HBM-bound links, while every wgrad only needs its layer's dy: launching the
+    wgrads on a second HIP stream lets the MFMA-bound wgrad kernels fill the matrix pipes while the chain's
+    HBM-bound kernels run.  Set QEA_OVERLAP=0 to keep everything on one stream."""
+
+    def __init__(self, device):
+        self.side = torch.cuda.Stream(device)
+
+    @property
+    def enabled(self):
+        return overlap_enabled()
+
+    def run(self, fn, *reads):
+        """fn() is enqueued on the side stream after everything already enqueued on the current stream; `reads`
+        are tensors it reads that were allocated on the current stream (kept from reuse until it has run)."""
+        if not self.enabled:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            fn()
+        for t in reads:
+            if t is not None:
+                t.record_stream(self.side)
+
+    def join(self):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            torch.cuda.current_stream().wait_event(ev)
 
 
 def prof_enable(klass, on=True):

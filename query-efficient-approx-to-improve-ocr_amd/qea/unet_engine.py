@@ -146,6 +146,10 @@ class UNetEngine:
         f = self.f
         training = ctx["training"]
         dout = dout.contiguous()
+        side = self.__dict__.get("_side")
+        if side is None or side.side is not None and side.side.device != dev:
+            side = ops.SideStream(dev)
+            self._side = side
 
         def block_bwd(blk, da2, ldda):
             """da2: grad w.r.t. the block output (pixel stride ldda).  Returns grad w.r.t. the block input
@@ -157,20 +161,20 @@ class UNetEngine:
             ops.bn_bwd(da2, ldda, s["out"], s["ldo"], s["y2"], cout, M, cout, P[blk.key(2, "gamma")], s["coef2"][0], s["coef2"][1],
                        training, G[blk.key(2, "gamma")], G[blk.key(2, "beta")], dy2, cout, accumulate=True, stat64=s["st2"])
             w2 = P[blk.key(2, "w")]
-            ops.conv_wgrad(dy2, s["a1"], G[blk.key(2, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cout, KH=3, KW=3, pad=(1, 1),
-                           ldp=cout, ldq=cout, accumulate=True)
+            side.run(lambda: ops.conv_wgrad(dy2, s["a1"], G[blk.key(2, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cout, KH=3, KW=3,
+                                            pad=(1, 1), ldp=cout, ldq=cout, accumulate=True), dy2)
             w2t = torch.empty(cout, 3, 3, cout, device=dev)
             ops.filter_flip_transpose(w2, w2t, cout, cout, 3, 3)
             da1 = torch.empty(M, cout, device=dev)
             ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout)
-            dy1 = dy2  # reuse
+            dy1 = torch.empty(M, cout, device=dev)       # (dy2 may still be read by its wgrad on the side stream)
             ops.bn_bwd(da1, cout, s["a1"], cout, s["y1"], cout, M, cout, P[blk.key(1, "gamma")], s["coef1"][0], s["coef1"][1],
                        training, G[blk.key(1, "gamma")], G[blk.key(1, "beta")], dy1, cout, accumulate=True, stat64=s["st1"])
             if cin == 1:
-                ops.conv_c1_wgrad(s["xin"], dy1, cout, G[blk.key(1, "w")], None, B, h, w, cout, accumulate=True)
+                side.run(lambda: ops.conv_c1_wgrad(s["xin"], dy1, cout, G[blk.key(1, "w")], None, B, h, w, cout, accumulate=True), dy1)
                 return None
-            ops.conv_wgrad(dy1, s["xin"], G[blk.key(1, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3, pad=(1, 1),
-                           ldp=cout, ldq=s["ldx"], accumulate=True)
+            side.run(lambda: ops.conv_wgrad(dy1, s["xin"], G[blk.key(1, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
+                                            pad=(1, 1), ldp=cout, ldq=s["ldx"], accumulate=True), dy1)
             w1t = torch.empty(cin, 3, 3, cout, device=dev)
             ops.filter_flip_transpose(P[blk.key(1, "w")], w1t, cout, cin, 3, 3)
             dxin = torch.empty(M, cin, device=dev)
@@ -190,9 +194,11 @@ class UNetEngine:
             cat, hh, ww, c = ctx["cats"][l]
             dcats[l] = dcat
             dprev, dcin, h, w = ctx["ups"][l]              # input of upconv_l: [B*h*w][dcin]
-            ops.colsum(dcat, 2 * c, B * hh * ww, c, G[f"upconv{l}.bias"], accumulate=True)
-            ops.conv_wgrad(dprev, dcat, G[f"upconv{l}.weight"], B=B, PH=h, PW=w, QH=hh, QW=ww, R=dcin, Cc=c, KH=2, KW=2,
-                           stride=(2, 2), ldp=dcin, ldq=2 * c, accumulate=True)
+            def up_grads(dcat=dcat, dprev=dprev, l=l, c=c, hh=hh, ww=ww, h=h, w=w, dcin=dcin):
+                ops.colsum(dcat, 2 * c, B * hh * ww, c, G[f"upconv{l}.bias"], accumulate=True)
+                ops.conv_wgrad(dprev, dcat, G[f"upconv{l}.weight"], B=B, PH=h, PW=w, QH=hh, QW=ww, R=dcin, Cc=c, KH=2, KW=2,
+                               stride=(2, 2), ldp=dcin, ldq=2 * c, accumulate=True)
+            side.run(up_grads, dcat)
             dd = torch.empty(B * h * w, dcin, device=dev)
             ops.conv_igemm(dcat, P[f"upconv{l}.weight"], dd, B=B, H=hh, W=ww, Cin=c, OH=h, OW=w, N=dcin, KH=2, KW=2, stride=(2, 2),
                            ldx=2 * c, ldy=dcin)
@@ -203,4 +209,5 @@ class UNetEngine:
             dskip = dcats[l][:, c:]
             ops.maxpool_bwd(cat[:, c:], 2 * c, dpool, c, dskip, 2 * c, B, hh, ww, c, 2, 2, relu_mask=False, accumulate=True)
             dpool = block_bwd(self.enc[l - 1], dskip, 2 * c)
+        side.join()
         return None
