@@ -1,7 +1,6 @@
 """TEST INFRASTRUCTURE ONLY — nn.Module shells around the functional CPU oracle, so that host logic
 written against `model(x)`, `.parameters()`, `.train()/.eval()`, `.state_dict()` (the trainers) can be
 exercised on a machine without a GPU by INJECTING these classes.  The product never imports them."""
-import torch
 import torch.nn as nn
 
 from . import model_oracle as mo

@@ -5,8 +5,6 @@ Phase A / Phase B of the preprocessor-training inner loop, area flavour
 where backward sits — SURVEY.md F6), on the functional oracle networks, torch CPU autograd,
 ATen's CPU ctc_loss and torch.optim.Adam.  Pinned by tests/golden/step_area_b4.npz.
 """
-import math
-
 import torch
 import torch.nn.functional as F
 

@@ -26,7 +26,7 @@ struct ConvArgs {
   int M, K, n_tiles, m_tiles;
 };
 
-constexpr int BK_MIN = 16;  // Cin must be a multiple of 32 (checked by the entry point); K-slice is 16 or 32
+// Cin must be a multiple of 32 (checked by the entry point); the K-slice BK is 16 or 32
 
 template <int BM, int BN, int WGM, int WGN, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
@@ -377,7 +377,7 @@ bool halo_eligible(const qea_conv_desc* d) {
   const int th = d->Cin == 32 ? 8 : 4;
   return ch && d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H &&
          d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->scale && !d->bias && !d->mask &&
-         !d->relu && !d->accumulate && d->ldy % 1 == 0;
+         !d->relu && !d->accumulate;
 }
 
 int launch_halo_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {

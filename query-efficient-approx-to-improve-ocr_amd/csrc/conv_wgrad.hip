@@ -39,8 +39,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   constexpr int STEPS = (BKP / 2) / WK;  // MFMA k-steps per wave per stage
   static_assert(WR * WC * WK == 4, "4 waves");
   static_assert(MI <= 2 && NJ <= 2, "fragment reads are b32 / b64");
-  constexpr int STAGE_FLOATS = BKP * (BR + BC);
-  constexpr int RED_FLOATS = (WK > 1) ? WK * BR * BC : 0;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ps = smem;                 // [2][BKP][BR]
@@ -159,7 +157,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   float* outp = a.out + (size_t)split * a.slab;
   const int ktot = taps * a.C;
   if constexpr (WK > 1) {
-    static_assert(RED_FLOATS <= 2 * STAGE_FLOATS || true, "");
     float* red = smem;  // [WK][BR][BC]   (staging buffers are dead after the last barrier)
 #pragma unroll
     for (int i = 0; i < MI; ++i)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
   }
 }
 
-// alpha (waves 0..3 of block y==0) and beta (block y==1) recursions, one block per (sample, pass)
+// alpha (blockIdx.y == 0) and beta (blockIdx.y == 1) recursions: one workgroup per (sample, pass), one thread per state
 __global__ __launch_bounds__(CTC_MAX_S) void ctc_alpha_beta_kernel(const float* __restrict__ lp, int ld_t, int ld_n,
                                                                     const int* __restrict__ targets, const long long* __restrict__ tg_off,
                                                                     const int* __restrict__ in_len, const int* __restrict__ tg_len, int T,

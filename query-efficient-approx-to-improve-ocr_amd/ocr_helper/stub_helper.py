@@ -3,8 +3,6 @@ ocr_helper/tess_helper.py:10-44): labels are a pure function of the image conten
 char_set symbols, '' -> empty_char, never longer than max_char_len, count_calls is maintained."""
 import zlib
 
-import torch
-
 import properties
 
 

@@ -26,10 +26,6 @@ def flat_state_of(param):
     return None
 
 
-def _phys_numel(t):
-    return t.numel()
-
-
 def _dense_strides(t):
     """Strides to keep when re-homing `t` (channels_last for 4-D filters, contiguous otherwise)."""
     if t.dim() == 4:

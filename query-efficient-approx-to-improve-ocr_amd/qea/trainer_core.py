@@ -17,8 +17,8 @@ import torch
 
 import properties
 from qea import dist as qdist
-from utils import (compare_labels, create_dirs, get_char_maps, get_ocr_helper, pred_to_string, save_all_jsons, save_img,
-                   set_bn_eval, set_random_seeds)
+from utils import (compare_labels, create_dirs, get_char_maps, get_ocr_helper, pred_to_string, save_all_jsons, set_bn_eval,
+                   set_random_seeds)
 
 
 class Backend:
