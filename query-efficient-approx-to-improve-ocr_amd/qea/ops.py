@@ -31,6 +31,8 @@ def _ptr(t):
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream): kernels on different streams never share one."""
+    if device.type != "cuda":
+        raise _lib.QeaError("qea ops need CUDA tensors (there is no CPU path)")
     key = (device.type, device.index, _stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
