@@ -10,6 +10,16 @@ def call_crnn(self, images):
     return scores, out_size
 
 
+def str_to_tensor(self, words):
+    """history words -> [window_size, max_char_len] index tensor, padded with the out-of-vocabulary index
+    len(char_set) (characters inside a word, and whole missing words) — reference tracking_utils.py:13-31."""
+    import properties
+    pad = len(properties.char_set)
+    rows = [[self.char_to_index[c] for c in w] + [pad] * max(0, properties.max_char_len - len(w)) for w in words]
+    rows += [[pad] * properties.max_char_len] * max(0, self.window_size - len(words))
+    return torch.tensor(rows).to(self.device)
+
+
 def generate_ctc_label(self, labels):
     y_size = torch.tensor([len(l) for l in labels], dtype=torch.int)
     y = torch.tensor([self.char_to_index[c] for c in "".join(labels)], dtype=torch.int)

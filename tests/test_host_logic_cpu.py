@@ -151,3 +151,21 @@ def test_file_datasets_roundtrip(tmp_path):
     assert (labels[0]["x_min"], labels[0]["y_min"]) == (10 + 106, 5 + 150)      # centred on the 400x512 canvas
     batch = PatchDataset.collate([pd[0]])
     assert batch[0].shape == (1, 1, 400, 512) and batch[2][0].endswith("doc1.png")
+
+
+def test_levenshtein_and_attention_weight_generators():
+    from label_tracking.tracking_methods import weightgenerator_factory
+    args = type("A", (), dict(decay_factor=0.5, window_size=3, query_dim=8, emb_dim=16, attn_activation="sigmoid"))()
+    hist = {"a": ["cat", "cat", "cut", "cat"], "b": ["x"], "c": []}
+    lev = weightgenerator_factory("levenshtein")(args, "cpu")
+    w = lev.gen_weights(hist, ["a", "b", "c", "missing"])
+    assert w.shape == (4, 4) and w[:, 0].tolist() == [1, 1, 1, 1]
+    # "a": window = [cat, cut, cat] (most recent first); cat vs {cut, cat}: mean 0.5 -> 0.5*(1-0.5/3)
+    assert abs(w[0, 1].item() - 0.5 * (1 - 0.5 / 3)) < 1e-6 and abs(w[0, 2].item() - 0.5 * (1 - 1 / 3)) < 1e-6
+    assert abs(w[1, 1].item() - 0.5) < 1e-6 and w[2, 1:].abs().sum() == 0 and w[3, 1:].abs().sum() == 0
+    torch.manual_seed(0)
+    att = weightgenerator_factory("self_attention")(args, "cpu", H.C2I)
+    wa = att.gen_weights(hist, ["a", "b", "c"])
+    assert wa.shape == (3, 4) and (wa[0, 1:] > 0).all() and (wa[0, 1:] < 1).all() and wa[1, 2:].abs().sum() == 0
+    assert set(att.attention_model.state_dict().keys()) == {"positional_encodings", "embedding", "Wq.weight", "Wq.bias",
+                                                            "loss_coef_layer.weight", "loss_coef_layer.bias"}

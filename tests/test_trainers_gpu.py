@@ -63,3 +63,21 @@ def test_patch_trainer_hip(tmp_path):
     st = torch.load(ck / "optim_prep_latest", weights_only=False)
     assert len(st["state"]) == len(list(t.prep_model.parameters())) and "exp_avg" in st["state"][0]
     assert set(json.load(open(tmp_path / "exp" / "cers" / "all_cers.json")).keys()) == set(names)
+
+
+@pytest.mark.parametrize("method", ["levenshtein", "self_attention"])
+def test_area_trainer_label_history_weightgens(tmp_path, method):
+    """--inner_limit_skip with the non-decaying weight generators: sample-wise CTC (reduction='none') on the HIP path
+    (the reference's patch trainer lacks primary_loss_fn_sample_wise; both trainers have it here)."""
+    from datasets.synthetic import SyntheticTextAreas
+    from train_nn_area import TrainNNPrep
+    tr = SyntheticTextAreas(16, seed=3, include_name=True, include_index=True)
+    cers_path = tmp_path / "cers.json"
+    json.dump({n: 0.5 for n in tr.names}, open(cers_path, "w"))
+    args = _args("a", tmp_path / "exp", batch_size=8, minibatch_subset="topKCER", minibatch_subset_prop=0.5, cers_ocr_path=str(cers_path),
+                 inner_limit=2, inner_limit_skip=True, window_size=3, weightgen_method=method, epoch=2)
+    t = TrainNNPrep(args, train_set=tr, val_set=SyntheticTextAreas(8, seed=4, include_name=True))
+    t.train()
+    flat = torch.cat([p.detach().flatten() for p in t.crnn_model.parameters()])
+    assert torch.isfinite(flat).all()
+    assert max(len(v) for v in t.tracked_labels.values()) == 2          # two epochs of history for the selected strips
