@@ -22,9 +22,11 @@ def _label(rng, lo=1, hi=12):
 
 
 class SyntheticTextAreas(torch.utils.data.Dataset):
-    def __init__(self, n, seed=0, include_name=True, include_index=False, size=properties.input_size):
+    def __init__(self, n, seed=0, include_name=True, include_index=False, size=properties.input_size, widths=None):
+        """widths: optional list of per-sample widths (multiples of 16) for variable-width lines (datasets/bucketing.py)"""
         self.n, self.seed, self.size = n, seed, size
         self.include_name, self.include_index = include_name, include_index
+        self.widths = list(widths) if widths is not None else None
         rng = np.random.RandomState(seed)
         self.labels = [_label(rng) for _ in range(n)]
         self.names = [f"{i}_{self.labels[i]}_synthetic.png" for i in range(n)]
@@ -35,7 +37,8 @@ class SyntheticTextAreas(torch.utils.data.Dataset):
     def __getitem__(self, i):
         i = int(i)
         g = torch.Generator().manual_seed(self.seed * 1000003 + i)
-        item = (_strokes((1,) + tuple(self.size), g), self.labels[i])
+        size = (self.size[0], self.widths[i]) if self.widths is not None else tuple(self.size)
+        item = (_strokes((1,) + size, g), self.labels[i])
         if self.include_name:
             item += (self.names[i],)
         if self.include_index:

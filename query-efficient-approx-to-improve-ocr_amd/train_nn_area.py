@@ -41,8 +41,15 @@ class TrainNNPrep(TrainerCore):
         tr_idx = torch.randperm(len(train_set))[: self.train_subset_size]
         if self.world > 1:                                    # shard the (identically seeded) permutation
             tr_idx = tr_idx[self.rank::self.world]
-        self.loader_train = torch.utils.data.DataLoader(train_set, batch_size=self.batch_size, drop_last=True,
-                                                        sampler=torch.utils.data.SubsetRandomSampler(tr_idx))
+        widths = getattr(train_set, "widths", None)
+        if widths is not None:                                # [new] variable-width lines: one width bucket per batch
+            from datasets.bucketing import BucketBatchSampler, bucket_collate
+            sub = torch.utils.data.Subset(train_set, tr_idx.tolist())
+            self.loader_train = torch.utils.data.DataLoader(
+                sub, collate_fn=bucket_collate, batch_sampler=BucketBatchSampler([widths[i] for i in tr_idx.tolist()], self.batch_size))
+        else:
+            self.loader_train = torch.utils.data.DataLoader(train_set, batch_size=self.batch_size, drop_last=True,
+                                                            sampler=torch.utils.data.SubsetRandomSampler(tr_idx))
         va_idx = torch.randperm(len(val_set))[: self.val_subset_size]
         self.loader_validation = torch.utils.data.DataLoader(val_set, batch_size=self.batch_size, drop_last=True,
                                                              sampler=torch.utils.data.SubsetRandomSampler(va_idx))

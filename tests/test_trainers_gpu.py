@@ -81,3 +81,22 @@ def test_area_trainer_label_history_weightgens(tmp_path, method):
     flat = torch.cat([p.detach().flatten() for p in t.crnn_model.parameters()])
     assert torch.isfinite(flat).all()
     assert max(len(v) for v in t.tracked_labels.values()) == 2          # two epochs of history for the selected strips
+
+
+def test_area_trainer_width_buckets(tmp_path):
+    """variable-width lines, one width bucket per batch (BASELINE configs[4] / SURVEY F8 extension)."""
+    from datasets.bucketing import bucket_of
+    from datasets.synthetic import SyntheticTextAreas
+    from train_nn_area import TrainNNPrep
+    widths = [96, 128, 160, 240, 256, 300, 400, 512] * 4
+    tr = SyntheticTextAreas(32, seed=5, include_name=True, include_index=True, widths=[(w + 15) // 16 * 16 for w in widths])
+    args = _args("a", tmp_path / "exp", batch_size=4, inner_limit=1)
+    t = TrainNNPrep(args, train_set=tr, val_set=SyntheticTextAreas(8, seed=6, include_name=True))
+    seen = set()
+    for images, labels, names, idx in t.loader_train:
+        assert images.shape[0] == 4 and images.shape[-1] in (128, 256, 384, 512)
+        assert all(bucket_of(tr.widths[i]) == images.shape[-1] for i in idx.tolist())
+        seen.add(images.shape[-1])
+    assert seen == {128, 256, 384, 512}
+    t.train()
+    assert torch.isfinite(torch.cat([p.detach().flatten() for p in t.prep_model.parameters()])).all()
