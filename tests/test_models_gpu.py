@@ -314,3 +314,45 @@ def test_replica_groups_equal_sequential_passes():
         assert _rel(a.grad, b.grad) < 2e-5, n
     for (n, a), (_, b) in zip(fused.named_buffers(), seq.named_buffers()):
         assert torch.equal(a, b), n
+
+
+def test_fused_adam_resume_matches_uninterrupted(tmp_path):
+    """optim_*_latest checkpoints (train_nn_patch.py:153-156,446-454): save after 2 steps, load into a fresh FusedAdam,
+    continue -> identical to 3 uninterrupted steps; the state_dict has torch.optim.Adam's layout and loads into it."""
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea.optim import FusedAdam
+    su = mo.seeded_state(mo.unet_state_shapes(), 13)
+    def make():
+        net = UNet()
+        net.load_state_dict(su)
+        return net.cuda()
+
+    def set_grads(net, k):
+        from qea.params import ensure_flat
+        ensure_flat(net).attach_grads()
+        for i, p in enumerate(net.parameters()):
+            p.grad.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(k * 1000 + i)).cuda())
+    a = make()
+    oa = FusedAdam(a.parameters(), lr=1e-3, weight_decay=5e-4)
+    for k in range(3):
+        set_grads(a, k)
+        oa.step()
+    b = make()
+    ob = FusedAdam(b.parameters(), lr=1e-3, weight_decay=5e-4)
+    for k in range(2):
+        set_grads(b, k)
+        ob.step()
+    torch.save(ob.state_dict(), tmp_path / "optim_prep_latest")
+    torch.save(b, tmp_path / "Prep_model")
+    c = torch.load(tmp_path / "Prep_model", weights_only=False).cuda()
+    oc = FusedAdam(c.parameters(), lr=1e-3, weight_decay=5e-4)
+    oc.load_state_dict(torch.load(tmp_path / "optim_prep_latest", weights_only=False))
+    set_grads(c, 2)
+    oc.step()
+    for (n, p), (_, q) in zip(a.named_parameters(), c.named_parameters()):
+        assert torch.equal(p, q), n
+    # the same file loads into torch's own Adam (layout compatibility in the other direction)
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in b.parameters()], lr=1e-3, weight_decay=5e-4)
+    ref.load_state_dict(torch.load(tmp_path / "optim_prep_latest", weights_only=False))
+    assert int(ref.state_dict()["state"][0]["step"]) == 2
