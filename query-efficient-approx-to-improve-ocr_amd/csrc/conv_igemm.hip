@@ -29,15 +29,17 @@ struct ConvArgs {
 // Cin must be a multiple of 32 (checked by the entry point); the K-slice BK is 16 or 32
 
 template <int BM, int BN, int WGM, int WGN, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int NT = WGM * WGN * 64;           // threads per workgroup (4 or 8 waves)
   constexpr int LDS_LD = BK + 4;               // padded LDS row (floats): keeps b128 reads conflict-free
   constexpr int KCH = BK / 4;                  // float4 per row of a K-slice
-  constexpr int RPP = 256 / KCH;               // rows covered per pass of the 256 threads
+  constexpr int RPP = NT / KCH;                // rows covered per pass of the workgroup's threads
   constexpr int TM = BM / WGM, TN = BN / WGN;  // wave tile
   constexpr int MI = TM / 32, NJ = TN / 32;    // 32x32 accumulator tiles per wave
   constexpr int A_LD = BM / RPP;               // float4 gathers per thread per stage (A)
   constexpr int B_LD = BN / RPP;               // (B)
-  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves per workgroup");
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BM][LDS_LD]
@@ -252,7 +254,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
     qea_set_error("qea_conv_igemm: grid %lld out of range", grid);
     return QEA_ERR_INVALID;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
   return QEA_OK;
 }
 
@@ -423,7 +425,18 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     // measured on MI355X (tools/bench_conv.py): the 16-deep K-slice (half the LDS, 4 workgroups per CU) wins
     // only when the grid is large enough to keep all of them busy
     const long long tiles128 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 128);
-    tile = halo_eligible(d) ? 4 : (d->N <= 32) ? 3 : (d->N <= 64) ? 2 : (tiles128 >= 2048) ? 5 : (tiles128 < 192) ? 6 : 1;
+    const long long tiles7 = (long long)qea_cdiv(a.M, 256) * qea_cdiv(d->N, 128);   // 256x128, 8 waves
+    const long long tiles8 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);   // 128x256, 8 waves
+    // 8-wave workgroups (twice the tile, 16-deep K-slice, 4 waves per SIMD) reach 130-135 TFLOP/s but need >= 4
+    // workgroups per CU to do so; below that the 4-wave tiles win (tools/bench_conv.py on MI355X)
+    if (halo_eligible(d)) tile = 4;
+    else if (d->N <= 32) tile = 3;
+    else if (d->N <= 64) tile = 2;
+    else if (d->N % 256 == 0 && tiles8 >= 1024) tile = 8;
+    else if (tiles7 >= 1024) tile = 7;
+    else if (tiles128 >= 2048) tile = 5;
+    else if (tiles128 < 192) tile = 6;
+    else tile = 1;
   }
   if (tile == 4 && !halo_eligible(d)) {
     qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, plain epilogue");
@@ -438,6 +451,8 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 3: rc = launch<256, 32, 4, 1, 32>(a, s); break;
     case 5: rc = launch<128, 128, 2, 2, 16>(a, s); break;
     case 6: rc = launch<128, 64, 2, 2, 32>(a, s); break;   // small grids: twice the workgroups of tile 1
+    case 7: rc = launch<256, 128, 4, 2, 16>(a, s); break;  // 8 waves
+    case 8: rc = launch<128, 256, 2, 4, 16>(a, s); break;  // 8 waves
     default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
   }
   if (rc != QEA_OK) return rc;
