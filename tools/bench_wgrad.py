@@ -12,12 +12,15 @@ from bench_conv import SHAPES  # noqa: E402
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
     tot_t = tot_f = 0.0
-    for (H, W, Cin, Cout) in SHAPES:
+    for (H, W, Cin, Cout), tile in [(sh, t) for sh in SHAPES for t in tiles]:
+        if tile in (1,) and min(Cin, Cout) < 128:
+            continue
         x = torch.randn(B, H, W, Cin, device="cuda")
         dy = torch.randn(B, H, W, Cout, device="cuda")
         dw = torch.empty(Cout, 3, 3, Cin, device="cuda")
-        kw = dict(B=B, PH=H, PW=W, QH=H, QW=W, R=Cout, Cc=Cin, KH=3, KW=3, pad=(1, 1), ldp=Cout, ldq=Cin)
+        kw = dict(B=B, PH=H, PW=W, QH=H, QW=W, R=Cout, Cc=Cin, KH=3, KW=3, pad=(1, 1), ldp=Cout, ldq=Cin, tile=tile)
         for _ in range(2):
             ops.conv_wgrad(dy, x, dw, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,7 +32,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         fl = 2.0 * B * H * W * Cout * 9 * Cin
-        print(f"H{H:3d} W{W:3d} Cin{Cin:4d} Cout{Cout:4d} {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
+        print(f"H{H:3d} W{W:3d} Cin{Cin:4d} Cout{Cout:4d} tile{tile} {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
         tot_t += ms
         tot_f += fl
     print(f"TOTAL {tot_t:.2f} ms  {tot_f / tot_t / 1e9:.1f} TF")
