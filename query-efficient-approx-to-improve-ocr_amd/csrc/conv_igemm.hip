@@ -427,13 +427,13 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     const long long tiles128 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 128);
     const long long tiles7 = (long long)qea_cdiv(a.M, 256) * qea_cdiv(d->N, 128);   // 256x128, 8 waves
     const long long tiles8 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);   // 128x256, 8 waves
-    // 8-wave workgroups (twice the tile, 16-deep K-slice, 4 waves per SIMD) reach 130-135 TFLOP/s but need >= 4
-    // workgroups per CU to do so; below that the 4-wave tiles win (tools/bench_conv.py on MI355X)
+    // 8-wave workgroups (twice the tile, 16-deep K-slice, 4 waves per SIMD) reach 124-135 TFLOP/s once the grid
+    // holds at least two of them per CU; below that the 4-wave tiles win (tools/bench_conv.py on MI355X)
     if (halo_eligible(d)) tile = 4;
     else if (d->N <= 32) tile = 3;
-    else if (d->N <= 64) tile = 2;
+    else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep)
     else if (d->N % 256 == 0 && tiles8 >= 1024) tile = 8;
-    else if (tiles7 >= 1024) tile = 7;
+    else if (tiles7 >= 512) tile = 7;
     else if (tiles128 >= 2048) tile = 5;
     else if (tiles128 < 192) tile = 6;
     else tile = 1;
@@ -453,6 +453,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 6: rc = launch<128, 64, 2, 2, 32>(a, s); break;   // small grids: twice the workgroups of tile 1
     case 7: rc = launch<256, 128, 4, 2, 16>(a, s); break;  // 8 waves
     case 8: rc = launch<128, 256, 2, 4, 16>(a, s); break;  // 8 waves
+    case 9: rc = launch<256, 64, 4, 1, 16>(a, s); break;   // tile 2 with half the LDS (3 workgroups per CU)
     default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
   }
   if (rc != QEA_OK) return rc;

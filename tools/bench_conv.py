@@ -14,6 +14,7 @@ SHAPES = [
     (8, 32, 64, 128), (8, 32, 128, 128), (8, 32, 256, 128), (4, 16, 128, 256), (4, 16, 256, 256),
     (4, 16, 512, 256), (2, 8, 256, 512), (2, 8, 512, 512),
     (16, 64, 64, 128), (8, 32, 128, 256), (8, 32, 256, 256), (4, 32, 256, 512), (4, 32, 512, 512),
+    (4, 16, 256, 512),
 ]
 
 
