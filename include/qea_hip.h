@@ -122,9 +122,11 @@ int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream);
  *                      updated in place with momentum and the UNBIASED variance.
  * qea_bn_eval_coeff  : the same four vectors from the running statistics (conv_bias, if given,
  *                      is folded into shift).
- * qea_bn_bwd         : dz = da * (a > 0) [a may be NULL: no ReLU]; dgamma = sum dz*xhat,
- *                      dbeta = sum dz; training: dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)),
- *                      eval: dy = scale*dz.  dy may alias da.
+ * qea_bn_bwd         : dz = da * relu'; dgamma = sum dz*xhat, dbeta = sum dz;
+ *                      training: dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)), eval: dy = scale*dz.
+ *                      dy may alias da.  relu' comes from a > 0 when a is given, or — without reading
+ *                      a — from y*relu_scale + relu_shift > 0 (the very fused multiply-add qea_bn_apply
+ *                      evaluates, hence the identical mask); both NULL: no ReLU.
  * stat64 (optional, [2][C] doubles): the batch mean and invstd unrounded; handing it back to
  * qea_bn_bwd keeps the per-channel constants of the backward in fp64 — they are common to every
  * pixel, so fp32 rounding of them is a CORRELATED error that later per-channel sums amplify by M.
@@ -140,8 +142,8 @@ int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* beta, const fl
                       float* invstd_out, float* scale_out, float* shift_out, void* stream);
 int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, int64_t M, int32_t C, const float* scale,
                  const float* shift, int32_t relu, void* stream);
-int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* y, int32_t ldy, int64_t M,
-               int32_t C, const float* gamma, const float* mean, const float* invstd, const double* stat64,
+int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* relu_scale,
+               const float* relu_shift, const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* mean, const float* invstd, const double* stat64,
                int32_t training, float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy,
                int32_t lddy, void* workspace, size_t workspace_bytes, void* stream);
 /* out[c] (+)= sum_m x[m][c]  — conv / linear / LSTM bias gradients */

@@ -25,7 +25,7 @@ ColGeom col_geom(long long M, int C) {
   g.rt = RED_THREADS / g.cols;
   if (g.rt < 1) g.rt = 1;
   long long want = (M + (long long)g.rt * 16 - 1) / ((long long)g.rt * 16);
-  if (want > 512) want = 512;
+  if (want > 1024) want = 1024;
   if (want < 1) want = 1;
   g.grid = (int)want;
   g.rows_per_block = (int)((M + g.grid - 1) / g.grid);
@@ -33,14 +33,20 @@ ColGeom col_geom(long long M, int C) {
   return g;
 }
 
+// The BatchNorm output before the ReLU, evaluated in ONE place so that the forward (bn_apply) and the mask the
+// backward recomputes from y agree bit for bit.
+__device__ __forceinline__ float bn_affine(float v, float sc, float sh) { return __fmaf_rn(v, sc, sh); }
+
 // MODE 0: s0 = sum x, s1 = sum x^2                                 (BN statistics)
-// MODE 1: dz = da * (a > 0 if a else 1); s0 = sum dz, s1 = sum dz * (y - mean) * invstd   (BN backward)
+// MODE 1: dz = da * relu'(.); s0 = sum dz, s1 = sum dz * (y - mean) * invstd   (BN backward)
+//         relu' from a > 0 when a is given, else from bn_affine(y, msc, msh) > 0 when msc is given (no read of a)
 // MODE 2: s0 = sum x                                               (bias gradient)
 template <int MODE>
 __global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ a,
                                                                   int lda, const float* __restrict__ y, int ldy,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                  const double* __restrict__ stat64, long long M, int C,
+                                                                  const double* __restrict__ stat64, const float* __restrict__ msc,
+                                                                  const float* __restrict__ msh, long long M, int C,
                                                                   int rows_per_block, int rt_n, double* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) double sred[];  // [rt_n][cols*4][2]
   const int cols = C / 4;
@@ -51,13 +57,19 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __r
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     double mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         mu[k] = stat64 ? stat64[ct * 4 + k] : (double)mean[ct * 4 + k];
         is[k] = stat64 ? stat64[C + ct * 4 + k] : (double)invstd[ct * 4 + k];
       }
+      if (!a && msc) {
+        sc = *reinterpret_cast<const f32x4*>(msc + ct * 4);
+        sh = *reinterpret_cast<const f32x4*>(msh + ct * 4);
+      }
     }
+#pragma unroll 2
     for (long long r = r0 + rt; r < r1; r += rt_n) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + ct * 4);
       if (MODE == 0) {
@@ -68,12 +80,15 @@ __global__ __launch_bounds__(RED_THREADS) void colreduce_kernel(const float* __r
         }
       } else if (MODE == 1) {
         f32x4 dz = v;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
         if (a) {
           const f32x4 av = *reinterpret_cast<const f32x4*>(a + r * lda + ct * 4);
 #pragma unroll
           for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
+        } else if (msc) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dz[k] = bn_affine(yv[k], sc[k], sh[k]) > 0.f ? dz[k] : 0.f;
         }
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           s0[k] += (double)dz[k];
@@ -171,8 +186,9 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ ws, int nblk, 
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, int C, long long M, const float* __restrict__ gamma,
-                                       const float* __restrict__ invstd, const double* __restrict__ stat64, int training, float* dgamma,
-                                       float* dbeta, int accumulate, double* k0, double* k1, double* k2) {
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       const double* __restrict__ stat64, int training, float* dgamma, float* dbeta, int accumulate,
+                                       double* k0, double* k1, double* k2) {
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   double s, q;
@@ -180,10 +196,16 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, 
   if ((threadIdx.x & 63) != 0) return;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
-  const float g = gamma ? gamma[c] : 1.f;
-  k0[c] = (double)g * (stat64 ? stat64[C + c] : (double)invstd[c]);  // dy = k0 * (dz - k1 - xhat * k2)
-  k1[c] = training ? s / (double)M : 0.0;
-  k2[c] = training ? q / (double)M : 0.0;
+  // dy = g*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)),  xhat = (y - mu) * invstd
+  //    = k0 * dz + k1 * y + k2     (fp64 per-channel constants, see bn_bwd_apply_kernel)
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  const double is = stat64 ? stat64[C + c] : (double)invstd[c];
+  const double mu = stat64 ? stat64[c] : (double)mean[c];
+  const double m0 = training ? s / (double)M : 0.0;
+  const double m1 = training ? q / (double)M : 0.0;
+  k0[c] = g * is;
+  k1[c] = -g * is * is * m1;
+  k2[c] = g * is * (mu * is * m1 - m0);
 }
 
 // ------------------------------------------------------------------ elementwise
@@ -200,42 +222,75 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, int ldy, float* __r
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      o[k] = v[k] * sc[k] + sh[k];
+      o[k] = bn_affine(v[k], sc[k], sh[k]);
       if (relu) o[k] = fmaxf(o[k], 0.f);
     }
     *reinterpret_cast<f32x4*>(a + r * lda + ct * 4) = o;
   }
 }
 
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ a, int lda,
-                                    const float* __restrict__ y, int ldy, float* __restrict__ dy, int lddy, long long M, int C,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd, const double* __restrict__ stat64,
-                                    const double* __restrict__ k0, const double* __restrict__ k1, const double* __restrict__ k2) {
-  // fp64 arithmetic with fp64 per-channel constants: mean(dz), mean(dz*xhat), mean and invstd are
-  // common to all pixels of a channel, so rounding them to fp32 puts a CORRELATED error into dy
-  // which the per-channel sums of the next layer amplify by the pixel count (measured 7e-4 on
-  // dbeta at M = 8192); ATen's CPU kernel also runs this in its fp64 accumulate type.
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ a, int lda,
+                                                                    const float* __restrict__ y, int ldy, float* __restrict__ dy, int lddy,
+                                                                    long long M, int C, const float* __restrict__ msc,
+                                                                    const float* __restrict__ msh, const double* __restrict__ k0,
+                                                                    const double* __restrict__ k1, const double* __restrict__ k2,
+                                                                    int rows_per_block, int rt_n) {
+  // dy = k0*dz + k1*y + k2 in fp64 with fp64 per-channel constants: mean(dz), mean(dz*xhat), mean and invstd are
+  // common to all pixels of a channel, so rounding them to fp32 puts a CORRELATED error into dy which the
+  // per-channel sums of the next layer amplify by the pixel count (measured 7e-4 on dbeta at M = 8192); ATen's
+  // CPU kernel also runs this in its fp64 accumulate type.  A thread keeps ONE float4 channel column (constants in
+  // registers) and walks rows, two per iteration to keep more bytes in flight.
   const int cols = C / 4;
-  const long long n = M * cols;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cols;
-    const int ct = (int)(i - r * cols);
-    f32x4 dz = *reinterpret_cast<const f32x4*>(da + r * ldda + ct * 4);
-    if (a) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(a + r * lda + ct * 4);
+  const int ct = threadIdx.x % cols, rt = threadIdx.x / cols;
+  if (rt >= rt_n) return;
+  double c0[4], c1[4], c2[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
-    }
-    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
+  for (int k = 0; k < 4; ++k) {
+    c0[k] = k0[ct * 4 + k];
+    c1[k] = k1[ct * 4 + k];
+    c2[k] = k2[ct * 4 + k];
+  }
+  f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  const bool remask = !a && msc;
+  if (remask) {
+    sc = *reinterpret_cast<const f32x4*>(msc + ct * 4);
+    sh = *reinterpret_cast<const f32x4*>(msh + ct * 4);
+  }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  auto one = [&](long long r, f32x4 dz, const f32x4 yv, const f32x4 av) {
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = ct * 4 + k;
-      const double mu = stat64 ? stat64[c] : (double)mean[c];
-      const double is = stat64 ? stat64[C + c] : (double)invstd[c];
-      o[k] = (float)(k0[c] * ((double)dz[k] - k1[c] - ((double)yv[k] - mu) * is * k2[c]));
+      float d = dz[k];
+      if (a) d = av[k] > 0.f ? d : 0.f;
+      else if (remask) d = bn_affine(yv[k], sc[k], sh[k]) > 0.f ? d : 0.f;
+      o[k] = (float)(c0[k] * (double)d + (c1[k] * (double)yv[k] + c2[k]));
     }
     *reinterpret_cast<f32x4*>(dy + r * lddy + ct * 4) = o;
+  };
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  long long r = r0 + rt;
+  for (; r + rt_n < r1; r += 2 * rt_n) {
+    const long long rb = r + rt_n;
+    const f32x4 dza = *reinterpret_cast<const f32x4*>(da + r * ldda + ct * 4);
+    const f32x4 dzb = *reinterpret_cast<const f32x4*>(da + rb * ldda + ct * 4);
+    const f32x4 ya = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
+    const f32x4 yb = *reinterpret_cast<const f32x4*>(y + rb * ldy + ct * 4);
+    f32x4 aa = zero, ab = zero;
+    if (a) {
+      aa = *reinterpret_cast<const f32x4*>(a + r * lda + ct * 4);
+      ab = *reinterpret_cast<const f32x4*>(a + rb * lda + ct * 4);
+    }
+    one(r, dza, ya, aa);
+    one(rb, dzb, yb, ab);
+  }
+  if (r < r1) {
+    const f32x4 dza = *reinterpret_cast<const f32x4*>(da + r * ldda + ct * 4);
+    const f32x4 ya = *reinterpret_cast<const f32x4*>(y + r * ldy + ct * 4);
+    const f32x4 aa = a ? *reinterpret_cast<const f32x4*>(a + r * lda + ct * 4) : zero;
+    one(r, dza, ya, aa);
   }
 }
 
@@ -367,7 +422,7 @@ extern "C" int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
   hipLaunchKernelGGL(colreduce_kernel<0>, dim3(g.grid), dim3(RED_THREADS), lds, s, y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                     nullptr, (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
+                     nullptr, nullptr, nullptr, (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, (const double*)workspace, g.grid, C,
                      (long long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out,
                      stat64);
@@ -394,8 +449,8 @@ extern "C" int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, 
   return QEA_OK;
 }
 
-extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* y, int32_t ldy, int64_t M, int32_t C,
-                          const float* gamma, const float* mean, const float* invstd, const double* stat64, int32_t training,
+extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* relu_scale, const float* relu_shift,
+                          const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* mean, const float* invstd, const double* stat64, int32_t training,
                           float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace,
                           size_t workspace_bytes, void* stream) {
   QEA_REQUIRE(da && y && mean && invstd && dy, "qea_bn_bwd: null pointer");
@@ -404,6 +459,8 @@ extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t
   if (rc) return rc;
   QEA_REQUIRE(workspace_bytes >= qea_colreduce_workspace_bytes(M, C), "qea_bn_bwd: workspace too small");
   QEA_REQUIRE(ldda % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!a || lda % 4 == 0), "qea_bn_bwd: strides must be multiples of 4");
+  QEA_REQUIRE(!a || !relu_scale, "qea_bn_bwd: give the ReLU mask either as a or as relu_scale/relu_shift, not both");
+  QEA_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "qea_bn_bwd: relu_scale and relu_shift go together");
   hipStream_t s = (hipStream_t)stream;
   double* ws = (double*)workspace;
   double* k0 = ws + (size_t)g.grid * C * 2;
@@ -411,11 +468,17 @@ extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t
   double* k2 = k1 + C;
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
   hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.grid), dim3(RED_THREADS), lds, s, da, ldda, a, lda, y, ldy, mean, invstd, stat64,
-                     (long long)M, C, g.rows_per_block, g.rt, ws);
+                     relu_scale, relu_shift, (long long)M, C, g.rows_per_block, g.rt, ws);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, (const double*)ws, g.grid, C, (long long)M, gamma,
-                     invstd, stat64, training, dgamma, dbeta, accumulate_param_grads, k0, k1, k2);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, s, da, ldda, a, lda, y, ldy, dy, lddy, (long long)M, C,
-                     mean, invstd, stat64, (const double*)k0, (const double*)k1, (const double*)k2);
+                     mean, invstd, stat64, training, dgamma, dbeta, accumulate_param_grads, k0, k1, k2);
+  // elementwise pass: same column-per-thread geometry, but up to 4096 workgroups (no partials to merge afterwards)
+  long long agrid = (M + (long long)g.rt * 8 - 1) / ((long long)g.rt * 8);
+  if (agrid > 4096) agrid = 4096;
+  if (agrid < 1) agrid = 1;
+  const int arows = (int)((M + agrid - 1) / agrid);
+  agrid = (M + arows - 1) / arows;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)agrid), dim3(RED_THREADS), 0, s, da, ldda, a, lda, y, ldy, dy, lddy, (long long)M,
+                     C, relu_scale, relu_shift, (const double*)k0, (const double*)k1, (const double*)k2, arows, g.rt);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
@@ -430,7 +493,7 @@ extern "C" int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, flo
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
   hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.grid), dim3(RED_THREADS), lds, s, x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                     nullptr, (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
+                     nullptr, nullptr, nullptr, (long long)M, C, g.rows_per_block, g.rt, (double*)workspace);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, (const double*)workspace, g.grid, C, out, accumulate);
   QEA_CHECK_LAUNCH();
   return QEA_OK;

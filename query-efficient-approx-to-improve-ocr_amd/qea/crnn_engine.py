@@ -243,10 +243,10 @@ class CRNNEngine:
             for gi in range(NG):
                 sl = slice(gi * Mg, (gi + 1) * Mg)
                 st = acts["st" + k]
-                ops.bn_bwd(da[sl], 512, acts["a" + k][sl], 512, acts["y" + k][sl], 512, Mg, 512, P[c + bn + ".weight"], coef[gi, 0],
+                ops.bn_bwd(da[sl], 512, None, 0, acts["y" + k][sl], 512, Mg, 512, P[c + bn + ".weight"], coef[gi, 0],
                            coef[gi, 1], bn_training, G[c + bn + ".weight"] if param_grads else None,
                            G[c + bn + ".bias"] if param_grads else None, dy_[sl], 512, accumulate=True,
-                           stat64=st[gi] if st is not None else None)
+                           stat64=st[gi] if st is not None else None, relu_scale=coef[gi, 2], relu_shift=coef[gi, 3])
             if param_grads:
                 def bn_conv_grads(dy_=dy_, name=name, src=src, cin=cin, M=M):
                     ops.colsum(dy_, 512, M, 512, G[c + name + ".bias"], accumulate=True)

@@ -157,9 +157,11 @@ def bn_apply(y, ldy, a, lda, M, C_, scale, shift, relu=True):
                "qea_bn_apply")
 
 
-def bn_bwd(da, ldda, a, lda, y, ldy, M, C_, gamma, mean, invstd, training, dgamma, dbeta, dy, lddy, accumulate=False, stat64=None):
+def bn_bwd(da, ldda, a, lda, y, ldy, M, C_, gamma, mean, invstd, training, dgamma, dbeta, dy, lddy, accumulate=False, stat64=None,
+           relu_scale=None, relu_shift=None):
+    """ReLU mask: pass the activation `a`, or a=None with the forward's scale/shift (mask recomputed from y, one tensor read less)."""
     wp, wn = _colws(M, C_, da.device)
-    _lib.check(_lib.lib().qea_bn_bwd(_ptr(da), ldda, _ptr(a), lda, _ptr(y), ldy, M, C_, _ptr(gamma), _ptr(mean),
+    _lib.check(_lib.lib().qea_bn_bwd(_ptr(da), ldda, _ptr(a), lda, _ptr(relu_scale), _ptr(relu_shift), _ptr(y), ldy, M, C_, _ptr(gamma), _ptr(mean),
                                      _ptr(invstd), _ptr(stat64), int(training), _ptr(dgamma), _ptr(dbeta), int(accumulate),
                                      _ptr(dy), lddy, wp, wn, _stream()), "qea_bn_bwd")
 

@@ -158,8 +158,10 @@ class UNetEngine:
             h, w, cin, cout = s["h"], s["w"], s["cin"], blk.cout
             M = B * h * w
             dy2 = torch.empty(M, cout, device=dev)
-            ops.bn_bwd(da2, ldda, s["out"], s["ldo"], s["y2"], cout, M, cout, P[blk.key(2, "gamma")], s["coef2"][0], s["coef2"][1],
-                       training, G[blk.key(2, "gamma")], G[blk.key(2, "beta")], dy2, cout, accumulate=True, stat64=s["st2"])
+            # ReLU mask recomputed from y with the forward's scale/shift: the activation is not re-read
+            ops.bn_bwd(da2, ldda, None, 0, s["y2"], cout, M, cout, P[blk.key(2, "gamma")], s["coef2"][0], s["coef2"][1],
+                       training, G[blk.key(2, "gamma")], G[blk.key(2, "beta")], dy2, cout, accumulate=True, stat64=s["st2"],
+                       relu_scale=s["coef2"][2], relu_shift=s["coef2"][3])
             w2 = P[blk.key(2, "w")]
             side.run(lambda: ops.conv_wgrad(dy2, s["a1"], G[blk.key(2, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cout, KH=3, KW=3,
                                             pad=(1, 1), ldp=cout, ldq=cout, accumulate=True), dy2)
@@ -168,8 +170,9 @@ class UNetEngine:
             da1 = torch.empty(M, cout, device=dev)
             ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout)
             dy1 = torch.empty(M, cout, device=dev)       # (dy2 may still be read by its wgrad on the side stream)
-            ops.bn_bwd(da1, cout, s["a1"], cout, s["y1"], cout, M, cout, P[blk.key(1, "gamma")], s["coef1"][0], s["coef1"][1],
-                       training, G[blk.key(1, "gamma")], G[blk.key(1, "beta")], dy1, cout, accumulate=True, stat64=s["st1"])
+            ops.bn_bwd(da1, cout, None, 0, s["y1"], cout, M, cout, P[blk.key(1, "gamma")], s["coef1"][0], s["coef1"][1],
+                       training, G[blk.key(1, "gamma")], G[blk.key(1, "beta")], dy1, cout, accumulate=True, stat64=s["st1"],
+                       relu_scale=s["coef1"][2], relu_shift=s["coef1"][3])
             if cin == 1:
                 side.run(lambda: ops.conv_c1_wgrad(s["xin"], dy1, cout, G[blk.key(1, "w")], None, B, h, w, cout, accumulate=True), dy1)
                 return None

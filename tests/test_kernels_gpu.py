@@ -56,6 +56,31 @@ def test_bn_train_fwd_bwd(C, M):
     assert rel_err(dgamma.cpu(), gr.grad) < 1e-5 and rel_err(dbeta.cpu(), br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("C,M", [(32, 2 * 32 * 128 + 5), (512, 777), (64, 4096)])
+def test_bn_bwd_mask_recomputed_from_y_is_bit_identical(C, M):
+    """qea_bn_bwd(relu_scale, relu_shift) must give exactly what qea_bn_bwd(a) gives (same mask, one tensor read less)."""
+    from qea import ops
+    g = torch.Generator().manual_seed(11)
+    dev = "cuda"
+    y = (torch.randn(M, C, generator=g) * 2 + 0.3).to(dev)
+    da = torch.randn(M, C, generator=g).to(dev)
+    gamma, beta = torch.randn(C, generator=g).to(dev), (0.01 * torch.randn(C, generator=g)).to(dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean, invstd, scale, shift = (torch.empty(C, device=dev) for _ in range(4))
+    stat64 = torch.empty(2, C, device=dev, dtype=torch.float64)
+    ops.bn_train_stats(y, C, M, C, gamma, beta, 1e-5, 0.1, rm, rv, mean, invstd, scale, shift, stat64)
+    a = torch.empty(M, C, device=dev)
+    ops.bn_apply(y, C, a, C, M, C, scale, shift, relu=True)
+    out = []
+    for kw in (dict(a=a, lda=C), dict(a=None, lda=0, relu_scale=scale, relu_shift=shift)):
+        dgamma, dbeta, dy = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(M, C, device=dev)
+        ops.bn_bwd(da, C, kw.pop("a"), kw.pop("lda"), y, C, M, C, gamma, mean, invstd, True, dgamma, dbeta, dy, C, stat64=stat64, **kw)
+        out.append((dgamma, dbeta, dy))
+    torch.cuda.synchronize()
+    for u, v in zip(*out):
+        assert torch.equal(u, v)
+
+
 def test_bn_eval_fwd_bwd():
     from qea import ops
     C, M = 512, 3 * 4 * 32
