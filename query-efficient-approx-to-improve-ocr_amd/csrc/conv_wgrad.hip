@@ -64,43 +64,72 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   const int m_end = min(a.M, m_begin + a.chunk);
   const int phw = a.PH * a.PW;
 
+  // ---- gather state.  256 is a multiple of BR/4 and BC/4, so a thread keeps ONE float4 channel column of P and
+  // of Q and its load slots differ only in the pixel row.  The pixel -> (image, row, column) split of a Q slot
+  // is done once and then advanced by BKP pixels per stage with two conditional carries: no divisions and no
+  // branches inside the main loop (out-of-range slots load from a safe address and are zeroed by a select), so
+  // the global loads, the LDS fragment reads and the MFMAs of a stage live in one basic block.
+  constexpr int RPP_P = 1024 / BR, RPP_Q = 1024 / BC;  // pixel rows covered by one pass of the 256 threads
+  const int cp = (tid % (BR / 4)) * 4, cq = (tid % (BC / 4)) * 4;
+  const int rowp = tid / (BR / 4), rowq = tid / (BC / 4);
+  const bool colp_ok = r0 + cp < a.R, colq_ok = c0 + cq < a.C;
+  const int qhw = a.QH * a.QW;
+  const int dq = BKP / a.PW, dr = BKP - dq * a.PW;  // BKP pixels = dq rows + dr columns
+  const int eq = dq / a.PH, er = dq - eq * a.PH;    //            = eq images + er rows + dr columns
+  int q_img[Q_LD], q_ph[Q_LD], q_pw[Q_LD];
+#pragma unroll
+  for (int j = 0; j < Q_LD; ++j) {
+    const int m = m_begin + rowq + j * RPP_Q;
+    const int b = m / phw;
+    const int rem = m - b * phw;
+    q_ph[j] = rem / a.PW;
+    q_pw[j] = rem - q_ph[j] * a.PW;
+    q_img[j] = b * qhw;
+  }
+  const float* p_ptr = a.p + (size_t)(m_begin + rowp) * a.ldp + (colp_ok ? r0 + cp : 0);
+  const float* q_col = a.q + (colq_ok ? c0 + cq : 0);
+
   f32x4 p_reg[P_LD], q_reg[Q_LD];
+  unsigned p_ok = 0, q_ok = 0;  // bit i: slot i holds real data
   auto gather = [&](int mbase) {
+    p_ok = 0;
+    q_ok = 0;
 #pragma unroll
     for (int i = 0; i < P_LD; ++i) {
-      const int f = tid + 256 * i;
-      const int row = f / (BR / 4), c4 = f % (BR / 4);
-      const int m = mbase + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end && r0 + c4 * 4 < a.R) v = *reinterpret_cast<const f32x4*>(a.p + (size_t)m * a.ldp + r0 + c4 * 4);
-      p_reg[i] = v;
+      const bool ok = colp_ok && (mbase + rowp + i * RPP_P < m_end);
+      p_reg[i] = *reinterpret_cast<const f32x4*>(ok ? p_ptr + (size_t)i * RPP_P * a.ldp : a.p);
+      p_ok |= (unsigned)ok << i;
     }
+    p_ptr += (size_t)BKP * a.ldp;
 #pragma unroll
-    for (int i = 0; i < Q_LD; ++i) {
-      const int f = tid + 256 * i;
-      const int row = f / (BC / 4), c4 = f % (BC / 4);
-      const int m = mbase + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end && c0 + c4 * 4 < a.C) {
-        const int b = m / phw;
-        const int rem = m - b * phw;
-        const int ph = rem / a.PW;
-        const int pw = rem - ph * a.PW;
-        const int qh = ph * a.stride_h + kh - a.pad_h;
-        const int qw = pw * a.stride_w + kw - a.pad_w;
-        if ((unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW)
-          v = *reinterpret_cast<const f32x4*>(a.q + ((size_t)(b * a.QH + qh) * a.QW + qw) * a.ldq + c0 + c4 * 4);
-      }
-      q_reg[i] = v;
+    for (int j = 0; j < Q_LD; ++j) {
+      const int qh = q_ph[j] * a.stride_h + kh - a.pad_h;
+      const int qw = q_pw[j] * a.stride_w + kw - a.pad_w;
+      const bool ok = colq_ok && (mbase + rowq + j * RPP_Q < m_end) && (unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW;
+      const int pix = ok ? q_img[j] + qh * a.QW + qw : 0;
+      q_reg[j] = *reinterpret_cast<const f32x4*>((ok ? q_col : a.q) + (size_t)pix * a.ldq);
+      q_ok |= (unsigned)ok << j;
+      // advance this slot by BKP pixels
+      int pw = q_pw[j] + dr, ph = q_ph[j] + er, img = q_img[j] + eq * qhw;
+      const bool cw = pw >= a.PW;
+      pw -= cw ? a.PW : 0;
+      ph += cw ? 1 : 0;
+      const bool chh = ph >= a.PH;
+      ph -= chh ? a.PH : 0;
+      img += chh ? qhw : 0;
+      q_pw[j] = pw;
+      q_ph[j] = ph;
+      q_img[j] = img;
     }
   };
   auto stage = [&](int buf) {
     float* pd = Ps + buf * BKP * BR;
     float* qd = Qs + buf * BKP * BC;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < P_LD; ++i) *reinterpret_cast<f32x4*>(pd + (tid + 256 * i) * 4) = p_reg[i];
+    for (int i = 0; i < P_LD; ++i) *reinterpret_cast<f32x4*>(pd + (tid + 256 * i) * 4) = ((p_ok >> i) & 1) ? p_reg[i] : zero;
 #pragma unroll
-    for (int i = 0; i < Q_LD; ++i) *reinterpret_cast<f32x4*>(qd + (tid + 256 * i) * 4) = q_reg[i];
+    for (int i = 0; i < Q_LD; ++i) *reinterpret_cast<f32x4*>(qd + (tid + 256 * i) * 4) = ((q_ok >> i) & 1) ? q_reg[i] : zero;
   };
 
   f32x16 acc[MI][NJ];
@@ -119,36 +148,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
     stage(0);
   }
   __syncthreads();
+  // fragment reads: a lane takes MI (NJ) CONSECUTIVE channels with one ds_read_b32/b64 and feeds them to
+  // MI (NJ) different accumulator tiles, i.e. tile i holds channels {MI*row + i} of the wave's block
+  // (interleaved, undone in the epilogue) — half the LDS instructions of one read per tile.  The fragments of
+  // k-step s+1 are read under the MFMAs of k-step s (register double buffer; hipcc does not pipeline them itself).
+  auto read_frag = [&](const float* ps, const float* qs, int s, float (&af)[MI], float (&bf)[NJ]) {
+    if constexpr (MI == 2) {
+      const float2 t = *reinterpret_cast<const float2*>(ps + s * 2 * BR);
+      af[0] = t.x;
+      af[1] = t.y;
+    } else {
+      af[0] = ps[s * 2 * BR];
+    }
+    if constexpr (NJ == 2) {
+      const float2 t = *reinterpret_cast<const float2*>(qs + s * 2 * BC);
+      bf[0] = t.x;
+      bf[1] = t.y;
+    } else {
+      bf[0] = qs[s * 2 * BC];
+    }
+  };
   for (int st = 0; st < nstage; ++st) {
     const int cur = st & 1;
     if (st + 1 < nstage) gather(m_begin + (st + 1) * BKP);
-    // fragment reads: a lane takes MI (NJ) CONSECUTIVE channels with one ds_read_b32/b64 and feeds them to
-    // MI (NJ) different accumulator tiles, i.e. tile i holds channels {MI*row + i} of the wave's block
-    // (interleaved, undone in the epilogue) — half the LDS instructions of one read per tile.
     const float* ps = Ps + cur * BKP * BR + (wk * (BKP / WK) + fh) * BR + wr * TR + fr * MI;
     const float* qs = Qs + cur * BKP * BC + (wk * (BKP / WK) + fh) * BC + wc * TCc + fr * NJ;
+    float af[2][MI], bf[2][NJ];
+    read_frag(ps, qs, 0, af[0], bf[0]);
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      float af[MI], bf[NJ];
-      if constexpr (MI == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(ps + s * 2 * BR);
-        af[0] = t.x;
-        af[1] = t.y;
-      } else {
-        af[0] = ps[s * 2 * BR];
-      }
-      if constexpr (NJ == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(qs + s * 2 * BC);
-        bf[0] = t.x;
-        bf[1] = t.y;
-      } else {
-        bf[0] = qs[s * 2 * BC];
-      }
+      const int c = s & 1, n = c ^ 1;
+      if (s + 1 < STEPS) read_frag(ps, qs, s + 1, af[n], bf[n]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+      if (s + 1 < STEPS) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // the two fragment reads of step s+1 ...
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);  // ... ahead of the MFMAs of step s
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
+      }
     }
     if (st + 1 < nstage) stage(cur ^ 1);
     __syncthreads();
