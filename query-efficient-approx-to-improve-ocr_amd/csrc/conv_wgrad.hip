@@ -64,72 +64,69 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   const int m_end = min(a.M, m_begin + a.chunk);
   const int phw = a.PH * a.PW;
 
-  // ---- gather state.  256 is a multiple of BR/4 and BC/4, so a thread keeps ONE float4 channel column of P and
-  // of Q and its load slots differ only in the pixel row.  The pixel -> (image, row, column) split of a Q slot
-  // is done once and then advanced by BKP pixels per stage with two conditional carries: no divisions and no
-  // branches inside the main loop (out-of-range slots load from a safe address and are zeroed by a select), so
-  // the global loads, the LDS fragment reads and the MFMAs of a stage live in one basic block.
-  constexpr int RPP_P = 1024 / BR, RPP_Q = 1024 / BC;  // pixel rows covered by one pass of the 256 threads
-  const int cp = (tid % (BR / 4)) * 4, cq = (tid % (BC / 4)) * 4;
-  const int rowp = tid / (BR / 4), rowq = tid / (BC / 4);
-  const bool colp_ok = r0 + cp < a.R, colq_ok = c0 + cq < a.C;
+  // ---- gather state.  The 256 threads cover the BKP pixel rows of a stage with TPR threads per row; a thread
+  // keeps ONE pixel row and loads P_LD float4 chunks of P and Q_LD of Q from it (chunk l + i*TPR), so a single
+  // pixel -> (image, row, column) split serves all its loads.  The split is done once and then advanced by BKP
+  // pixels per stage with two conditional carries: no divisions and no branches inside the main loop
+  // (out-of-range slots load from a safe address and are zeroed by a select).
+  constexpr int TPR = 256 / BKP;
+  static_assert(P_LD * TPR * 4 == BR && Q_LD * TPR * 4 == BC, "chunks per thread");
+  const int grow = tid / TPR, gl = tid % TPR;
   const int qhw = a.QH * a.QW;
   const int dq = BKP / a.PW, dr = BKP - dq * a.PW;  // BKP pixels = dq rows + dr columns
   const int eq = dq / a.PH, er = dq - eq * a.PH;    //            = eq images + er rows + dr columns
-  int q_img[Q_LD], q_ph[Q_LD], q_pw[Q_LD];
-#pragma unroll
-  for (int j = 0; j < Q_LD; ++j) {
-    const int m = m_begin + rowq + j * RPP_Q;
+  int g_img, g_ph, g_pw;
+  {
+    const int m = m_begin + grow;
     const int b = m / phw;
     const int rem = m - b * phw;
-    q_ph[j] = rem / a.PW;
-    q_pw[j] = rem - q_ph[j] * a.PW;
-    q_img[j] = b * qhw;
+    g_ph = rem / a.PW;
+    g_pw = rem - g_ph * a.PW;
+    g_img = b * qhw;
   }
-  const float* p_ptr = a.p + (size_t)(m_begin + rowp) * a.ldp + (colp_ok ? r0 + cp : 0);
-  const float* q_col = a.q + (colq_ok ? c0 + cq : 0);
+  unsigned colp_ok = 0, colq_ok = 0;  // bit i: chunk i of this thread lies inside R (C)
+#pragma unroll
+  for (int i = 0; i < P_LD; ++i) colp_ok |= (unsigned)(r0 + (gl + i * TPR) * 4 < a.R) << i;
+#pragma unroll
+  for (int i = 0; i < Q_LD; ++i) colq_ok |= (unsigned)(c0 + (gl + i * TPR) * 4 < a.C) << i;
+  const float* p_ptr = a.p + (size_t)(m_begin + grow) * a.ldp + r0 + gl * 4;
+  const float* q_col = a.q + c0 + gl * 4;
 
   f32x4 p_reg[P_LD], q_reg[Q_LD];
   unsigned p_ok = 0, q_ok = 0;  // bit i: slot i holds real data
   auto gather = [&](int mbase) {
-    p_ok = 0;
-    q_ok = 0;
+    const bool row_ok = mbase + grow < m_end;
+    const int qh = g_ph * a.stride_h + kh - a.pad_h;
+    const int qw = g_pw * a.stride_w + kw - a.pad_w;
+    const bool pix_ok = row_ok && (unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW;
+    const float* q_ptr = q_col + (size_t)(pix_ok ? g_img + qh * a.QW + qw : 0) * a.ldq;
+    p_ok = row_ok ? colp_ok : 0u;
+    q_ok = pix_ok ? colq_ok : 0u;
 #pragma unroll
-    for (int i = 0; i < P_LD; ++i) {
-      const bool ok = colp_ok && (mbase + rowp + i * RPP_P < m_end);
-      p_reg[i] = *reinterpret_cast<const f32x4*>(ok ? p_ptr + (size_t)i * RPP_P * a.ldp : a.p);
-      p_ok |= (unsigned)ok << i;
-    }
+    for (int i = 0; i < P_LD; ++i) p_reg[i] = *reinterpret_cast<const f32x4*>(((p_ok >> i) & 1) ? p_ptr + i * TPR * 4 : a.p);
+#pragma unroll
+    for (int i = 0; i < Q_LD; ++i) q_reg[i] = *reinterpret_cast<const f32x4*>(((q_ok >> i) & 1) ? q_ptr + i * TPR * 4 : a.q);
     p_ptr += (size_t)BKP * a.ldp;
-#pragma unroll
-    for (int j = 0; j < Q_LD; ++j) {
-      const int qh = q_ph[j] * a.stride_h + kh - a.pad_h;
-      const int qw = q_pw[j] * a.stride_w + kw - a.pad_w;
-      const bool ok = colq_ok && (mbase + rowq + j * RPP_Q < m_end) && (unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW;
-      const int pix = ok ? q_img[j] + qh * a.QW + qw : 0;
-      q_reg[j] = *reinterpret_cast<const f32x4*>((ok ? q_col : a.q) + (size_t)pix * a.ldq);
-      q_ok |= (unsigned)ok << j;
-      // advance this slot by BKP pixels
-      int pw = q_pw[j] + dr, ph = q_ph[j] + er, img = q_img[j] + eq * qhw;
-      const bool cw = pw >= a.PW;
-      pw -= cw ? a.PW : 0;
-      ph += cw ? 1 : 0;
-      const bool chh = ph >= a.PH;
-      ph -= chh ? a.PH : 0;
-      img += chh ? qhw : 0;
-      q_pw[j] = pw;
-      q_ph[j] = ph;
-      q_img[j] = img;
-    }
+    // advance the pixel by BKP
+    int pw = g_pw + dr, ph = g_ph + er, img = g_img + eq * qhw;
+    const bool cw = pw >= a.PW;
+    pw -= cw ? a.PW : 0;
+    ph += cw ? 1 : 0;
+    const bool chh = ph >= a.PH;
+    ph -= chh ? a.PH : 0;
+    img += chh ? qhw : 0;
+    g_pw = pw;
+    g_ph = ph;
+    g_img = img;
   };
   auto stage = [&](int buf) {
-    float* pd = Ps + buf * BKP * BR;
-    float* qd = Qs + buf * BKP * BC;
+    float* pd = Ps + buf * BKP * BR + grow * BR + gl * 4;
+    float* qd = Qs + buf * BKP * BC + grow * BC + gl * 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < P_LD; ++i) *reinterpret_cast<f32x4*>(pd + (tid + 256 * i) * 4) = ((p_ok >> i) & 1) ? p_reg[i] : zero;
+    for (int i = 0; i < P_LD; ++i) *reinterpret_cast<f32x4*>(pd + i * TPR * 4) = ((p_ok >> i) & 1) ? p_reg[i] : zero;
 #pragma unroll
-    for (int i = 0; i < Q_LD; ++i) *reinterpret_cast<f32x4*>(qd + (tid + 256 * i) * 4) = ((q_ok >> i) & 1) ? q_reg[i] : zero;
+    for (int i = 0; i < Q_LD; ++i) *reinterpret_cast<f32x4*>(qd + i * TPR * 4) = ((q_ok >> i) & 1) ? q_reg[i] : zero;
   };
 
   f32x16 acc[MI][NJ];
