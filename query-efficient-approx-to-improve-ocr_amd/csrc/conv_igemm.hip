@@ -284,18 +284,28 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restri
   const int b = bid / tiles_y;
   const int x0 = tx * TW, y0 = ty * TH;
 
-  // ---- halo load (zero outside the image) ----
+  // ---- halo load (zero outside the image): every global load of the thread is issued before the first LDS write
+  // (a load -> wait -> write loop serialises ~12 memory latencies, as long as the whole MFMA phase of the tile) ----
   constexpr int C4 = CIN / 4;
+  constexpr int NLD = (HH * HW_ * C4 + 255) / 256;
   const float* xb = x + (size_t)b * H * W * ldx;
-  for (int e = tid; e < HH * HW_ * C4; e += 256) {
+  f32x4 hv[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i;
     const int c4 = e % C4;
     const int q = e / C4;
     const int hx = q % HW_, hy = q / HW_;
     const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-      v = *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * ldx + c4 * 4);
-    *reinterpret_cast<f32x4*>(halo + q * PS + c4 * 4) = v;
+    const bool ok = e < HH * HW_ * C4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)iy * W + ix) * ldx + c4 * 4 : x);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    hv[i] = ok ? v : zero;
+  }
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i;
+    if (e < HH * HW_ * C4) *reinterpret_cast<f32x4*>(halo + (e / C4) * PS + (e % C4) * 4) = hv[i];
   }
   __syncthreads();
 
@@ -325,6 +335,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restri
   for (int ks = 0; ks < KSTEPS; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < KSTEPS) load_b(ks + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next step's filter loads AHEAD of this step's MFMAs (hipcc sinks them to just-in-time)
     const int tap = ks / KC, c0 = (ks % KC) * 32;
     const int kh = tap / 3, kw = tap % 3;
     const float* a_src = halo + ((wave * MI + kh) * HW_ + fr + kw) * PS + c0 + fh * 4;

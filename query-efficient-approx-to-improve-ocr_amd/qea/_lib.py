@@ -10,7 +10,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_DIR, "libqea_hip.so")
+LIB_PATH = os.environ.get("QEA_HIP_LIB") or os.path.join(PKG_DIR, "libqea_hip.so")   # QEA_HIP_LIB: A/B a second build
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "qea_hip.h")
 
 _lib = None

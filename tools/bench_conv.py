@@ -33,16 +33,18 @@ def main():
                               B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad_h=1, pad_w=1,
                               stride_h=1, stride_w=1, ldx=Cin, ldy=Cout, ldmask=0, relu=0, accumulate=0,
                               out_mode=0, tile=tile)
-            for _ in range(2):
+            for _ in range(4):
                 _lib.check(L.qea_conv_igemm(C.byref(d), s))
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 5
-            e0.record()
-            for _ in range(n):
-                L.qea_conv_igemm(C.byref(d), s)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / n
+            ms = 1e9
+            for _rep in range(3):                      # best of three batches (the first launches after an allocation run slow)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n = 5
+                e0.record()
+                for _ in range(n):
+                    L.qea_conv_igemm(C.byref(d), s)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = min(ms, e0.elapsed_time(e1) / n)
             fl = 2.0 * B * H * W * Cout * 9 * Cin
             print(f"H{H:3d} W{W:3d} Cin{Cin:4d} Cout{Cout:4d} tile{tile} {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
             if tile == tiles[0]:

@@ -15,7 +15,7 @@ def main():
     tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
     tot_t = tot_f = 0.0
     for (H, W, Cin, Cout), tile in [(sh, t) for sh in SHAPES for t in tiles]:
-        if (tile in (1, 9) and min(Cin, Cout) < 128) or (tile in (7, 10) and (Cout < 128 or Cin != 64)) or (tile in (8, 11) and (Cin < 128 or Cout != 64)):
+        if (tile in (1, 9, 12, 13) and min(Cin, Cout) < 128) or (tile in (7, 10) and (Cout < 128 or Cin != 64)) or (tile in (8, 11) and (Cin < 128 or Cout != 64)):
             continue
         x = torch.randn(B, H, W, Cin, device="cuda")
         dy = torch.randn(B, H, W, Cout, device="cuda")
