@@ -90,9 +90,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvAr
   const int KT = p.KH * p.KW * cin_steps;
 
   f32x4 a_reg[A_LD], b_reg[B_LD];
+  // K order: channel slice outermost, the KH*KW taps innermost.  The taps of one slice re-read (shifted) the same
+  // few KB of input, which then come from L1/L2; tap-outermost order re-streamed the whole input tile per tap and
+  // the PMC pass showed 5x the algorithmic HBM fetch on the 512-channel layers.
+  const int ntaps = p.KH * p.KW;
   auto gather = [&](int kt) {
-    const int tap = kt / cin_steps;
-    const int c0 = (kt - tap * cin_steps) * BK;
+    const int cs = kt / ntaps;
+    const int tap = kt - cs * ntaps;
+    const int c0 = cs * BK;
     const int kh = tap / p.KW;
     const int kw = tap - kh * p.KW;
 #pragma unroll

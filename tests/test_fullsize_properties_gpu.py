@@ -49,8 +49,10 @@ def test_batch_split_invariance_and_oracle_subset():
         lp = crnn(img)
         img_h = torch.cat([prep(x[:200]), prep(x[200:])])
         lp_h = torch.cat([crnn(img[:, :][:72]), crnn(img[72:])], dim=1)
-    assert (img - img_h).abs().max().item() < 2e-6
-    assert (lp - lp_h).abs().max().item() < 2e-5
+    # a different batch picks different conv tiles (16- or 32-deep K slices = another fp32 summation order):
+    # the outputs agree to accumulated rounding, not bit for bit
+    assert (img - img_h).abs().max().item() < 2e-5
+    assert (lp - lp_h).abs().max().item() < 1e-4
     idx = torch.tensor([0, 17, 127, 128, 255, 256, 300, 511])
     Pu, Bu = mo.split_state(su, requires_grad=False)
     Pc, Bc = mo.split_state(sc, requires_grad=False)
