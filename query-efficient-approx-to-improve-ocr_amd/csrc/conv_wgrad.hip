@@ -50,9 +50,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   const int wrc = wave % (WR * WC);
   const int wr = wrc / WC, wc = wrc % WC;
 
-  // tile decode: all tiles of one split are consecutive block ids (-> shared L2 lines)
-  const int split = blockIdx.y;
-  const int tile = blockIdx.x;
+  // block -> (split, tile): every XCD (blocks with equal id % 8 under round-robin dispatch) takes a contiguous run
+  // of the (split-major) work list, so the r x tap x c tiles of one pixel chunk run on ONE XCD at about the same
+  // time and its P / Q rows are fetched into that L2 once instead of once per tap and XCD (PMC: 8x the algorithmic
+  // fetch on the 64/128-channel levels with the plain blockIdx order)
+  const int vid = qea_xcd_swizzle(blockIdx.x, a.tiles * a.splits);
+  const int split = vid / a.tiles;
+  const int tile = vid - split * a.tiles;
   const int taps = a.KH * a.KW;
   const int c_tile = tile % a.c_tiles;
   const int tap = (tile / a.c_tiles) % taps;
@@ -350,7 +354,7 @@ void launch(const WgArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tiles, a.splits), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles * (unsigned)a.splits), dim3(256), lds, s, a);
 }
 
 template <int BR, int BC, int WR, int WC, int WK, int BKP = 32>
