@@ -228,8 +228,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvAr
         } else {
           o = orow * p.ldy + n;
         }
-        if (p.scale) v *= p.scale[n];
-        if (p.bias) v += p.bias[nb];
+        if (p.scale && p.bias) v = __fmaf_rn(v, p.scale[n], p.bias[nb]);  // the very fma qea_bn_apply evaluates
+        else if (p.scale) v *= p.scale[n];
+        else if (p.bias) v += p.bias[nb];
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.mask) {
           const size_t mo = (p.out_mode == QEA_OUT_CONVT) ? (o / p.ldy) * p.ldmask + nb : orow * p.ldmask + n;
@@ -275,7 +276,8 @@ int launch(const ConvArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int TH>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ y, int B, int H, int W, int ldx, int ldy) {
+                                                           float* __restrict__ y, int B, int H, int W, int ldx, int ldy,
+                                                           const float* __restrict__ scale, const float* __restrict__ bias, int relu) {
   constexpr int TW = 32, PS = CIN + 4, HW_ = TW + 2, HH = TH + 2;
   constexpr int MI = TH / 4, NJ = COUT / 32, KC = CIN / 32;
   extern __shared__ __attribute__((aligned(16))) float halo[];  // [HH][HW_][PS]
@@ -359,7 +361,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restri
     }
   }
 
-  // ---- store: row (= pixel x) = (r&3) + 8*(r>>2) + 4*fh, col (= channel) = fr ----
+  // ---- store: row (= pixel x) = (r&3) + 8*(r>>2) + 4*fh, col (= channel) = fr; optional per-channel
+  // scale/bias (+ReLU) epilogue = eval-mode BatchNorm folded into the conv ----
+  float esc[NJ], ebi[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    esc[j] = scale ? scale[j * 32 + fr] : 1.f;
+    ebi[j] = bias ? bias[j * 32 + fr] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float* yrow = y + ((size_t)(b * H + y0 + wave * MI + i) * W + x0) * ldy;
@@ -367,7 +376,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) {
       const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) yrow[(size_t)px * ldy + j * 32 + fr] = acc[i][j][r];
+      for (int j = 0; j < NJ; ++j) {
+        float v = acc[i][j][r];
+        if (scale && bias) v = __fmaf_rn(v, esc[j], ebi[j]);
+        else if (scale) v *= esc[j];
+        else if (bias) v += ebi[j];
+        if (relu) v = fmaxf(v, 0.f);
+        yrow[(size_t)px * ldy + j * 32 + fr] = v;
+      }
     }
   }
 }
@@ -386,7 +402,7 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
     qea_set_error("qea_conv_igemm(halo): grid %lld out of range", grid);
     return QEA_ERR_INVALID;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, a.w, a.y, a.B, a.H, a.W, a.ldx, a.ldy);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, a.w, a.y, a.B, a.H, a.W, a.ldx, a.ldy, a.scale, a.bias, a.relu);
   return QEA_OK;
 }
 
@@ -394,8 +410,7 @@ bool halo_eligible(const qea_conv_desc* d) {
   const bool ch = (d->Cin == 32 || d->Cin == 64) && (d->N == 32 || d->N == 64);
   const int th = d->Cin == 32 ? 8 : 4;
   return ch && d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H &&
-         d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->scale && !d->bias && !d->mask &&
-         !d->relu && !d->accumulate;
+         d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->mask && !d->accumulate;
 }
 
 int launch_halo_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
@@ -455,7 +470,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     else tile = 1;
   }
   if (tile == 4 && !halo_eligible(d)) {
-    qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, plain epilogue");
+    qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate");
     return QEA_ERR_INVALID;
   }
   qea_prof_begin(QEA_PROF_CONV_IGEMM, s);

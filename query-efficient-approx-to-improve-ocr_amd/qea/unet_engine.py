@@ -19,6 +19,7 @@ from .params import ensure_flat
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+FUSE_EVAL_BN = True   # tests flip this to compare the fused inference epilogue with the two-pass form
 
 
 class _Block:
@@ -55,6 +56,15 @@ class UNetEngine:
         cout = blk.cout
         M = B * H * W
         w = P[blk.key(i, "w")]
+        if not training and saved is None and cin != 1 and FUSE_EVAL_BN:
+            # inference (Phase A's cleaner pass, validation): eval-mode BatchNorm + ReLU ride in the conv epilogue — the
+            # same fused multiply-add bn_apply evaluates, so the result is bit-identical to the two-pass form
+            coef = torch.empty(4, cout, device=dev)
+            ops.bn_eval_coeff(cout, P[blk.key(i, "gamma")], P[blk.key(i, "beta")], Bf[blk.key(i, "rm")], Bf[blk.key(i, "rv")], BN_EPS,
+                              None, coef[0], coef[1], coef[2], coef[3])
+            ops.conv_igemm(x, w, out, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=ldo,
+                           scale=coef[2], bias=coef[3], relu=True)
+            return
         y = torch.empty(M, cout, device=dev)
         if cin == 1:
             ops.conv_c1_fwd(x, w, None, y, cout, B, H, W, cout, relu=False)

@@ -356,3 +356,21 @@ def test_fused_adam_resume_matches_uninterrupted(tmp_path):
     ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in b.parameters()], lr=1e-3, weight_decay=5e-4)
     ref.load_state_dict(torch.load(tmp_path / "optim_prep_latest", weights_only=False))
     assert int(ref.state_dict()["state"][0]["step"]) == 2
+
+
+def test_unet_inference_fused_bn_epilogue_is_bit_identical():
+    """Eval-mode no-grad forward folds BatchNorm+ReLU into the conv epilogue (halo and generic kernels): same bits as conv -> bn_apply."""
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea import unet_engine
+    net = _load(UNet(), mo.unet_state_shapes, 1).eval()
+    x = H.synth_images(6, 77).cuda()
+    outs = []
+    for fuse in (True, False):
+        unet_engine.FUSE_EVAL_BN = fuse
+        try:
+            with torch.no_grad():
+                outs.append(net(x).clone())
+        finally:
+            unet_engine.FUSE_EVAL_BN = True
+    assert torch.equal(outs[0], outs[1])
