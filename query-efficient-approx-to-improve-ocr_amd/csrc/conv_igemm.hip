@@ -2,10 +2,10 @@
 //
 //   C[m][n] = sum_k A[m][k] * Wt[n][k]      m = (b,oh,ow) output pixel, n = output channel,
 //                                            k = (kh,kw,c) filter tap x input channel.
-// A is never materialised: every K-slice of 32 channels of one filter tap is gathered
-// straight from the NHWC input (zero outside the image) into an LDS tile, the filter slice
-// into a second one, and each wave runs v_mfma_f32_32x32x2_f32 over its 64x64 (or 64x32)
-// accumulator block.  K is consumed in a permuted order inside every group of 8 so that a
+// A is never materialised: every K-slice (16 or 32 channels of one filter tap; channel slice
+// outermost, taps innermost) is gathered straight from the NHWC input (zero outside the image)
+// into an LDS tile, the filter slice into a second one, and each of the 4 or 8 waves runs
+// v_mfma_f32_32x32x2_f32 over its 64x64 (or 64x32) accumulator block.  K is consumed in a permuted order inside every group of 8 so that a
 // lane fetches its 4 A (B) values of four consecutive MFMAs with one ds_read_b128:
 // lane (r = l&31, h = l>>5), MFMA step s  ->  k = 4h + s  on both operands.
 //

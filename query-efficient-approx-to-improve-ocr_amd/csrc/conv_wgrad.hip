@@ -7,10 +7,12 @@
 // linear / LSTM:   KH = KW = 1
 //
 // The reduction index is the pixel m, the slow dimension of both operands, so tiles are
-// staged pixel-major ([32 pixels][channels]) and MFMA fragments are read column-wise with
-// ds_read_b32 (lane l: channel l&31 of pixel 2s + (l>>5) at MFMA step s).  The pixel range is
-// split over blockIdx.y; partial results go to a workspace slab per split and a second,
-// order-fixed pass sums them (bit-reproducible, no float atomics).
+// staged pixel-major ([16 or 32 pixels][channels]) and MFMA fragments are read column-wise
+// (lane l: channels {MI*(l&31) + i} of pixel 2s + (l>>5) at MFMA step s, one ds_read_b32/b64).
+// The pixel range is cut into splits sized so that tiles x splits fills the chip a whole number
+// of times; the (split, tile) work list is handed to the XCDs in contiguous runs; partial
+// results go to a workspace slab per split and a second, order-fixed pass sums them
+// (bit-reproducible, no float atomics).
 //
 // Roofline: MFMA-bound for wide layers (2*M*R*taps*C flops), L2/HBM-leaning for the 32/64-
 // channel UNet levels where each pixel carries only 2*R*C*taps flops per (R+C)*4 bytes.
