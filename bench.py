@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--skip-crnn-wgrad", action="store_true",
                     help="skip the CRNN weight gradients the reference computes but discards when --update_CRNN is off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="record the step into a hipGraph and time replays (single GPU; pays off at small --batch, where the step "
+                         "is bound by host launch time; at the default batch the step is GPU-bound)")
     ap.add_argument("--full-step", action="store_true",
                     help="also time Phase A + Phase B (TopKCER prop 0.95, inner_limit 4 jitter replicas, CRNN BN-train fwd/bwd, "
                          "Adam(CRNN)) and report it as `full_step` (the headline `value` stays the Phase-B metric)")
@@ -135,7 +138,9 @@ def main():
     crnn.register_backward_hook(crnn.backward_hook)
     if args.skip_crnn_wgrad:
         crnn.__dict__["_qea_skip_param_grads"] = True
-    opt_p = FusedAdam(prep.parameters(), lr=5e-5, weight_decay=0)
+    if args.graph and use_dist:
+        raise SystemExit("bench.py: --graph is a single-GPU option")
+    opt_p = FusedAdam(prep.parameters(), lr=5e-5, weight_decay=0, capturable=args.graph)
     ctc = CTCLoss()
     mse = torch.nn.MSELoss()
     B = args.batch
@@ -143,6 +148,11 @@ def main():
     ins = torch.full((B,), 31, dtype=torch.int32)
     ones = torch.ones(B, 1, 32, 128, device=dev)
     fs = ensure_flat(prep)
+    if args.graph:                                   # capturable form: device-resident targets, nothing read on the host
+        ctc.max_target_length = int(lens.max())
+        y_s, ins_s, lens_s = y.to(dev), ins.to(dev), lens.to(dev)
+    else:
+        y_s, ins_s, lens_s = y, ins, lens
 
     def step():
         prep.train()
@@ -154,7 +164,7 @@ def main():
         crnn.zero_grad()
         img = prep(x)
         lp = crnn(img)
-        loss = ctc(lp, y, ins, lens) + mse(img, ones)
+        loss = ctc(lp, y_s, ins_s, lens_s) + mse(img, ones)
         loss.backward()
         if use_dist:
             dist.all_reduce(fs.grad)                 # one RCCL all-reduce of the flat 31 MB UNet gradient
@@ -207,10 +217,15 @@ def main():
         if rank == 0:
             print(f"[bench] warm-up {i + 1}/{args.warmup} done", file=sys.stderr, flush=True)
     # ---- timed region: the production configuration (weight gradients overlapped on a side stream), no event overhead
+    run = step
+    if args.graph:
+        from qea.graph import GraphedStep
+        run = GraphedStep(step, warmup=0)
+        run()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     fence()
     dt = time.perf_counter() - t0
     if rank == 0:
@@ -280,7 +295,7 @@ def main():
             "config": {"workload": "Phase-B step (UNet train-BN -> CRNN BN-eval -> CTC mean + MSE -> backward -> Adam(UNet)) on "
                                    "synthetic POS-style 32x128 patches, BASELINE configs[1] batch",
                        "batch_per_gpu": B, "global_batch": B * world, "crnn_wgrad": not args.skip_crnn_wgrad,
-                       "parallelism": f"dp{world}", "loss": float(loss.item())},
+                       "parallelism": f"dp{world}", "loss": float(loss.item()), "hipgraph": bool(args.graph)},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM: conv fwd/dgrad, "
                                                       "convT, LSTM/linear GEMMs)",
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,

@@ -227,6 +227,13 @@ int qea_ctc_loss(const float* lp, int32_t ld_t, int32_t ld_n, const int32_t* tar
  * g' = g*grad_scale + wd*p; m,v update; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
 int qea_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+/* The same update with the step count held on the device (torch.optim.Adam(capturable=True)): step[0] (a float,
+ * as torch keeps it) is incremented by a one-thread kernel which also writes the two bias-correction
+ * coefficients to coef[0..1]; no launch argument depends on the step count, so the pair of launches can be
+ * recorded into a hipGraph and replayed. */
+int qea_adam_step_capturable(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float* step, float* coef, float grad_scale,
+                             void* stream);
 
 /* AddGaussianNoice (transform_helper.py:33-45) for R replicas of K images fused into the batch
  * dim: out[r*K+k] = clamp(img[k] - coef*sigma[r*K+k]*N(0,1), 0, 1); Philox4x32-10 keyed by

@@ -7,8 +7,15 @@
 namespace {
 
 // ------------------------------------------------------------------ Adam
+// coef (optional, device): {step_size, bc2_sqrt} written by adam_coeff_kernel — the capturable form, whose launch
+// arguments do not depend on the step count
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                            float beta1, float beta2, float eps, float weight_decay, float step_size, float bc2_sqrt, float grad_scale) {
+                            float beta1, float beta2, float eps, float weight_decay, float step_size, float bc2_sqrt, float grad_scale,
+                            const float* __restrict__ coef) {
+  if (coef) {
+    step_size = coef[0];
+    bc2_sqrt = coef[1];
+  }
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -237,7 +244,26 @@ int grid_for(long long n, int cap = 4096) {
   return (int)g;
 }
 
+// step += 1;  coef = {lr / (1 - beta1^step), sqrt(1 - beta2^step)}   (same fp64 formulas as the host path)
+__global__ void adam_coeff_kernel(float* step, float* coef, float lr, float beta1, float beta2) {
+  const double t = (double)step[0] + 1.0;
+  step[0] = (float)t;
+  coef[0] = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+  coef[1] = (float)sqrt(1.0 - pow((double)beta2, t));
+}
+
 }  // namespace
+
+extern "C" int qea_adam_step_capturable(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                        float eps, float weight_decay, float* step, float* coef, float grad_scale, void* stream) {
+  QEA_REQUIRE(p && g && m && v && step && coef && n > 0, "qea_adam_step_capturable: bad arguments");
+  QEA_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "qea_adam_step_capturable: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_coeff_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, coef, lr, beta1, beta2);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
+                     weight_decay, 0.f, 1.f, grad_scale, (const float*)coef);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
 
 extern "C" int qea_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int64_t step, float grad_scale, void* stream) {
@@ -246,7 +272,7 @@ extern "C" int qea_adam_step(float* p, const float* g, float* m, float* v, int64
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
-                     weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
+                     weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale, (const float*)nullptr);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

@@ -255,6 +255,12 @@ def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_sca
                                         grad_scale, _stream()), "qea_adam_step")
 
 
+def adam_step_capturable(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, coef, grad_scale=1.0):
+    """step: 1-element CUDA float tensor (incremented on the device), coef: 2-element CUDA float scratch."""
+    _lib.check(_lib.lib().qea_adam_step_capturable(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, weight_decay,
+                                                   _ptr(step), _ptr(coef), grad_scale, _stream()), "qea_adam_step_capturable")
+
+
 def jitter(img, sigma, out, noise_out, K, R, HW, coef, seed, offset):
     _lib.check(_lib.lib().qea_jitter(_ptr(img), _ptr(sigma), _ptr(out), _ptr(noise_out), K, R, HW, coef, seed, offset,
                                      _stream()), "qea_jitter")

@@ -4,7 +4,10 @@ Same hyper-parameters and update rule as torch.optim.Adam as used by the referen
 (train_nn_patch.py:146-152: betas (0.9, 0.999), eps 1e-8, L2 weight decay folded into the
 gradient; train_nn_area.py:149-154: weight_decay 0).  state_dict() has torch.optim.Adam's layout
 (per-parameter 'step', 'exp_avg', 'exp_avg_sq'), so the reference's optim_*_latest checkpoints
-(train_nn_patch.py:153-156,446-454) load and save unchanged."""
+(train_nn_patch.py:153-156,446-454) load and save unchanged.
+
+capturable=True (torch.optim.Adam's flag of the same name) keeps the step count on the device, so that a whole
+training step can be recorded into a hipGraph (qea/graph.py) and replayed."""
 import torch
 
 from . import ops
@@ -13,10 +16,12 @@ from ._lib import QeaError
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self._flat = {}
+        self.capturable = bool(capturable)
+        self._coef = {}
 
     def _flat_group(self, gi, group):
         """(FlatState, exp_avg flat, exp_avg_sq flat) when the group is exactly one flat model."""
@@ -59,6 +64,18 @@ class FusedAdam(torch.optim.Optimizer):
                 fs, m, v = ent
                 fs.attach_grads()
                 st0 = self.state[ps[0]]
+                if self.capturable:
+                    step_t = st0["step"]
+                    if not (step_t.is_cuda and step_t.dtype == torch.float32 and all(self.state[p]["step"] is step_t for p in ps)):
+                        step_t = torch.tensor([float(step_t)], dtype=torch.float32, device=fs.data.device)
+                        for p in ps:                         # ONE device counter shared by the parameters of the flat model
+                            self.state[p]["step"] = step_t
+                    coef = self._coef.get(gi)
+                    if coef is None:
+                        coef = self._coef[gi] = torch.zeros(2, dtype=torch.float32, device=fs.data.device)
+                    ops.adam_step_capturable(fs.data, fs.grad, m, v, fs.total, group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                             step_t, coef)
+                    continue
                 step = int(st0["step"].item()) + 1 if st0["step"].is_cuda else int(st0["step"]) + 1
                 ops.adam_step(fs.data, fs.grad, m, v, fs.total, group["lr"], b1, b2, group["eps"], group["weight_decay"], step)
                 for p in ps:

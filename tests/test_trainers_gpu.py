@@ -5,6 +5,8 @@ import os
 import pytest
 import torch
 
+import helpers as H
+
 pytestmark = pytest.mark.gpu
 
 
@@ -100,3 +102,60 @@ def test_area_trainer_width_buckets(tmp_path):
     assert seen == {128, 256, 384, 512}
     t.train()
     assert torch.isfinite(torch.cat([p.detach().flatten() for p in t.prep_model.parameters()])).all()
+
+
+def test_hipgraph_replay_of_a_phase_b_step_equals_eager():
+    """A whole Phase-B step (UNet+CRNN fwd, CTC+MSE, backward incl. the wgrad side stream, capturable Adam) recorded into a
+    hipGraph and replayed gives bit-identical weights to the same steps launched eagerly."""
+    from models.model_crnn import CRNN
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea.graph import GraphedStep
+    from qea.loss import CTCLoss
+    from qea.optim import FusedAdam
+    B = 8
+    x = H.synth_images(B, 5).cuda()
+    labels = H.synth_labels(B, 6, 1, 9)
+    y, ysz = H.encode(labels)
+    y_d, ysz_d = y.cuda(), ysz.cuda()
+    ins_d = torch.full((B,), 31, dtype=torch.int32, device="cuda")
+    ones = torch.ones(B, 1, 32, 128, device="cuda")
+
+    def build():
+        prep = UNet()
+        prep.load_state_dict(mo.seeded_state(mo.unet_state_shapes(), 3))
+        crnn = CRNN(95, False)
+        crnn.load_state_dict(mo.seeded_state(mo.crnn_state_shapes(), 4))
+        prep, crnn = prep.cuda(), crnn.cuda()
+        crnn.register_backward_hook(crnn.backward_hook)
+        opt = FusedAdam(prep.parameters(), lr=5e-4, capturable=True)
+        ctc = CTCLoss()
+        ctc.max_target_length = int(ysz.max())
+        prep.train()
+        crnn.train()
+        for m in crnn.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+
+        def step():
+            prep.zero_grad()
+            crnn.zero_grad()
+            img = prep(x)
+            loss = ctc(crnn(img), y_d, ins_d, ysz_d) + torch.nn.functional.mse_loss(img, ones)
+            loss.backward()
+            opt.step()
+            return loss
+        return prep, step
+
+    n_warm, n_replay = 2, 3
+    prep_e, step_e = build()
+    for _ in range(n_warm + n_replay):
+        loss_e = step_e()
+    prep_g, step_g = build()
+    g = GraphedStep(step_g, warmup=n_warm)
+    for _ in range(n_replay):
+        loss_g = g()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss_g).all() and torch.equal(loss_g, loss_e)
+    for (k, a), (_, b) in zip(prep_e.state_dict().items(), prep_g.state_dict().items()):
+        assert torch.equal(a, b), k
