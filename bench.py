@@ -123,6 +123,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the ranks of one node
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from models.model_crnn import CRNN

@@ -22,6 +22,7 @@ def init_from_env(device=None):
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or (dist.is_available() and dist.is_initialized()):
         return world()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on these hosts
     if device is not None and device.type == "cuda":
         dist.init_process_group("nccl", device_id=device)
     else:
