@@ -28,6 +28,8 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between ranks; must be set before HIP starts
+
 import torch  # noqa: E402
 
 CHARS = 95
@@ -123,7 +125,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the ranks of one node
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from models.model_crnn import CRNN
