@@ -11,6 +11,8 @@
 //
 // Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); 2*M*N*K algorithmic flops/launch.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -25,6 +27,63 @@ struct ConvArgs {
   int ldx, ldy, ldmask, relu, accumulate, out_mode;
   int M, K, n_tiles, m_tiles;
 };
+
+// Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Order: v = acc*scale + bias; relu; mask; accumulate; store (out_mode remaps).
+template <int MI, int NJ, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&acc)[MI][NJ], int m0, int n0, int wm, int wn, int fr, int fh) {
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (m >= p.M) continue;
+      size_t orow;  // output row (pixel) index for QEA_OUT_NHWC / TBC
+      int cb = 0, ch = 0, cw = 0;
+      if (p.out_mode == QEA_OUT_NHWC) {
+        orow = (size_t)m;
+      } else if (p.out_mode == QEA_OUT_TBC) {
+        const int b = m / p.OW;
+        const int ow = m - b * p.OW;
+        orow = (size_t)ow * p.B + b;
+      } else {
+        cb = m / ohw;
+        const int rem = m - cb * ohw;
+        ch = rem / p.OW;
+        cw = rem - ch * p.OW;
+        orow = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * TN + j * 32 + fr;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r];
+        size_t o;
+        int nb = n;
+        if (p.out_mode == QEA_OUT_CONVT) {
+          const int co_n = p.N >> 2;
+          const int ab = n / co_n;
+          nb = n - ab * co_n;
+          const size_t opix = ((size_t)cb * (2 * p.OH) + 2 * ch + (ab >> 1)) * (2 * p.OW) + 2 * cw + (ab & 1);
+          o = opix * p.ldy + nb;
+        } else {
+          o = orow * p.ldy + n;
+        }
+        if (p.scale && p.bias) v = __fmaf_rn(v, p.scale[n], p.bias[nb]);  // the very fma qea_bn_apply evaluates
+        else if (p.scale) v *= p.scale[n];
+        else if (p.bias) v += p.bias[nb];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.mask) {
+          const size_t mo = (p.out_mode == QEA_OUT_CONVT) ? (o / p.ldy) * p.ldmask + nb : orow * p.ldmask + n;
+          v = (p.mask[mo] > 0.f) ? v : 0.f;
+        }
+        if (p.accumulate) v += p.y[o];
+        p.y[o] = v;
+      }
+    }
+  }
+}
 
 // Cin must be a multiple of 32 (checked by the entry point); the K-slice BK is 16 or 32
 
@@ -190,57 +249,194 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvAr
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  conv_epilogue<MI, NJ, TM, TN>(p, acc, m0, n0, wm, wn, fr, fh);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENTAL (tile ids 20-22, never chosen automatically): the same implicit GEMM with every fp32 operand split
+// into three bf16 planes x = h + m + l (|x - (h+m+l)| <= 2^-24 |x|) and each product formed by SIX bf16 MFMAs
+// (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll terms are < 2^-23 |ab|) accumulated in fp32:
+// v_mfma_f32_32x32x16_bf16 sustains 1800 TFLOP/s on this part (tools/micro/mfma_rate.hip), i.e. a 300 TFLOP/s
+// fp32-equivalent ceiling against 154 for v_mfma_f32_32x32x2_f32.  One K stage = 16 channels of one tap = one MFMA
+// k-step; LDS holds [plane][row][16 bf16 + 8 pad] (48-byte rows: conflict-free ds_read_b128).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+  for (int k = 0; k < 4; ++k) {
+    const __bf16 hk = (__bf16)v[k];
+    const float r1 = v[k] - (float)hk;
+    const __bf16 mk = (__bf16)r1;
+    const float r2 = r1 - (float)mk;
+    h[k] = hk;
+    m[k] = mk;
+    l[k] = (__bf16)r2;
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const ConvArgs p) {
+  constexpr int BK = 16;
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int ROWB = 24;                     // bf16 elements per LDS row (16 + 8 pad = 48 bytes)
+  constexpr int KCH = BK / 4;                  // float4 per row of a K-slice
+  constexpr int RPP = NT / KCH;                // rows covered per pass of the workgroup's threads
+  constexpr int TM = BM / WGM, TN = BN / WGN;  // wave tile
+  constexpr int MI = TM / 32, NJ = TN / 32;
+  constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem);  // [2][3][BM][ROWB]
+  __bf16* Bs = As + 2 * 3 * BM * ROWB;           // [2][3][BN][ROWB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nwg = p.m_tiles * p.n_tiles;
+  const int tile = qea_xcd_swizzle(blockIdx.x, nwg);
+  const int tile_m = tile / p.n_tiles, tile_n = tile % p.n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lrow = tid / KCH, kc = tid % KCH;
+  int a_pix[A_LD], a_ih0[A_LD], a_iw0[A_LD];
+  const int ohw = p.OH * p.OW;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      if (m >= p.M) continue;
-      size_t orow;  // output row (pixel) index for QEA_OUT_NHWC / TBC
-      int cb = 0, ch = 0, cw = 0;
-      if (p.out_mode == QEA_OUT_NHWC) {
-        orow = (size_t)m;
-      } else if (p.out_mode == QEA_OUT_TBC) {
-        const int b = m / p.OW;
-        const int ow = m - b * p.OW;
-        orow = (size_t)ow * p.B + b;
-      } else {
-        cb = m / ohw;
-        const int rem = m - cb * ohw;
-        ch = rem / p.OW;
-        cw = rem - ch * p.OW;
-        orow = 0;
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * TN + j * 32 + fr;
-        if (n >= p.N) continue;
-        float v = acc[i][j][r];
-        size_t o;
-        int nb = n;
-        if (p.out_mode == QEA_OUT_CONVT) {
-          const int co_n = p.N >> 2;
-          const int ab = n / co_n;
-          nb = n - ab * co_n;
-          const size_t opix = ((size_t)cb * (2 * p.OH) + 2 * ch + (ab >> 1)) * (2 * p.OW) + 2 * cw + (ab & 1);
-          o = opix * p.ldy + nb;
-        } else {
-          o = orow * p.ldy + n;
-        }
-        if (p.scale && p.bias) v = __fmaf_rn(v, p.scale[n], p.bias[nb]);  // the very fma qea_bn_apply evaluates
-        else if (p.scale) v *= p.scale[n];
-        else if (p.bias) v += p.bias[nb];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.mask) {
-          const size_t mo = (p.out_mode == QEA_OUT_CONVT) ? (o / p.ldy) * p.ldmask + nb : orow * p.ldmask + n;
-          v = (p.mask[mo] > 0.f) ? v : 0.f;
-        }
-        if (p.accumulate) v += p.y[o];
-        p.y[o] = v;
-      }
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + lrow + RPP * i;
+    if (m < p.M) {
+      const int b = m / ohw;
+      const int rem = m - b * ohw;
+      const int oh = rem / p.OW;
+      const int ow = rem - oh * p.OW;
+      a_pix[i] = b * p.H * p.W;
+      a_ih0[i] = oh * p.stride_h - p.pad_h;
+      a_iw0[i] = ow * p.stride_w - p.pad_w;
+    } else {
+      a_pix[i] = -1;
+      a_ih0[i] = 0;
+      a_iw0[i] = 0;
     }
   }
+  const float* b_ptr[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int n = n0 + lrow + RPP * j;
+    b_ptr[j] = (n < p.N) ? (p.w + (size_t)n * p.K + kc * 4) : nullptr;
+  }
+  const int ntaps = p.KH * p.KW;
+  const int KT = ntaps * (p.Cin / BK);
+
+  f32x4 a_reg[A_LD], b_reg[B_LD];
+  auto gather = [&](int kt) {
+    const int cs = kt / ntaps;
+    const int tap = kt - cs * ntaps;
+    const int c0 = cs * BK;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+      const bool ok = (a_pix[i] >= 0) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_pix[i] + ih * p.W + iw) * p.ldx + c0 + kc * 4);
+      a_reg[i] = v;
+    }
+    const int koff = tap * p.Cin + c0;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ptr[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + koff);
+      b_reg[j] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+    __bf16* a_dst = As + (size_t)buf * 3 * BM * ROWB;
+    __bf16* b_dst = Bs + (size_t)buf * 3 * BN * ROWB;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      bf16x4 h, m, l;
+      split3(a_reg[i], h, m, l);
+      const int o = (lrow + RPP * i) * ROWB + kc * 4;
+      *reinterpret_cast<bf16x4*>(a_dst + o) = h;
+      *reinterpret_cast<bf16x4*>(a_dst + BM * ROWB + o) = m;
+      *reinterpret_cast<bf16x4*>(a_dst + 2 * BM * ROWB + o) = l;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      bf16x4 h, m, l;
+      split3(b_reg[j], h, m, l);
+      const int o = (lrow + RPP * j) * ROWB + kc * 4;
+      *reinterpret_cast<bf16x4*>(b_dst + o) = h;
+      *reinterpret_cast<bf16x4*>(b_dst + BN * ROWB + o) = m;
+      *reinterpret_cast<bf16x4*>(b_dst + 2 * BN * ROWB + o) = l;
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  gather(0);
+  stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) gather(kt + 1);
+    const __bf16* a_src = As + (size_t)cur * 3 * BM * ROWB + (wm * TM + fr) * ROWB + fh * 8;
+    const __bf16* b_src = Bs + (size_t)cur * 3 * BN * ROWB + (wn * TN + fr) * ROWB + fh * 8;
+    bf16x8 af[3][MI], bf[3][NJ];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(a_src + pl * BM * ROWB + i * 32 * ROWB);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(b_src + pl * BN * ROWB + j * 32 * ROWB);
+    }
+    // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+      }
+    if (kt + 1 < KT) stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  conv_epilogue<MI, NJ, TM, TN>(p, acc, m0, n0, wm, wn, fr, fh);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_bf3(const ConvArgs& a, hipStream_t s) {
+  ConvArgs p = a;
+  p.m_tiles = qea_cdiv(p.M, BM);
+  p.n_tiles = qea_cdiv(p.N, BN);
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * 24 * 2;
+  auto kern = conv_igemm_bf3_kernel<BM, BN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const long long grid = (long long)p.m_tiles * p.n_tiles;
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    qea_set_error("qea_conv_igemm: grid %lld out of range", grid);
+    return QEA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
+  return QEA_OK;
 }
 
 template <int BM, int BN, int WGM, int WGN, int BK>
@@ -406,6 +602,15 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
   return QEA_OK;
 }
 
+// QEA_MFMA=f32 keeps every product on v_mfma_f32_32x32x2_f32; anything else (default) allows the split-bf16 tiles
+bool split_bf16_enabled() {
+  static const int on = [] {
+    const char* e = getenv("QEA_MFMA");
+    return (e && strcmp(e, "f32") == 0) ? 0 : 1;
+  }();
+  return on != 0;
+}
+
 bool halo_eligible(const qea_conv_desc* d) {
   const bool ch = (d->Cin == 32 || d->Cin == 64) && (d->N == 32 || d->N == 64);
   const int th = d->Cin == 32 ? 8 : 4;
@@ -460,8 +665,16 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     const long long tiles8 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);   // 128x256, 8 waves
     // 8-wave workgroups (twice the tile, 16-deep K-slice, 4 waves per SIMD) reach 124-135 TFLOP/s once the grid
     // holds at least two of them per CU; below that the 4-wave tiles win (tools/bench_conv.py on MI355X)
+    // split-bf16 tiles (20-23) for every layer of 64+ output channels unless QEA_MFMA=f32 asks for the native fp32 MFMA:
+    // 160-186 TFLOP/s against 110-134, and closer to the fp64 result than the fp32 instruction (fewer accumulator roundings)
+    const long long tiles21 = (long long)qea_cdiv(a.M, 256) * qea_cdiv(d->N, 128);
+    const long long tiles22 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);
     if (halo_eligible(d)) tile = 4;
     else if (d->N <= 32) tile = 3;
+    else if (split_bf16_enabled() && d->N <= 64) tile = 23;
+    else if (split_bf16_enabled() && d->N % 256 == 0 && tiles22 >= 256) tile = 22;
+    else if (split_bf16_enabled() && tiles21 >= 256) tile = 21;
+    else if (split_bf16_enabled()) tile = 20;
     else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep)
     else if (d->N % 256 == 0 && tiles8 >= 1024) tile = 8;
     else if (tiles7 >= 512) tile = 7;
@@ -485,6 +698,10 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 7: rc = launch<256, 128, 4, 2, 16>(a, s); break;  // 8 waves
     case 8: rc = launch<128, 256, 2, 4, 16>(a, s); break;  // 8 waves
     case 9: rc = launch<256, 64, 4, 1, 16>(a, s); break;   // tile 2 with half the LDS (3 workgroups per CU)
+    case 20: rc = launch_bf3<128, 128, 2, 2>(a, s); break;  // split-bf16 forms
+    case 21: rc = launch_bf3<256, 128, 4, 2>(a, s); break;
+    case 22: rc = launch_bf3<128, 256, 2, 4>(a, s); break;
+    case 23: rc = launch_bf3<256, 64, 4, 1>(a, s); break;
     default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
   }
   if (rc != QEA_OK) return rc;
