@@ -7,6 +7,25 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x = h + m + l with three bf16 values, |x - (h+m+l)| <= 2^-24 |x| (each residual is exact in fp32).  A product of two
+// such triples keeps hh, hm, mh, hl, lh, mm (six bf16 MFMAs, fp32 accumulate); the dropped ml, lm, ll are < 2^-23 |ab|.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void qea_split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const __bf16 hk = (__bf16)v[k];
+    const float r1 = v[k] - (float)hk;
+    const __bf16 mk = (__bf16)r1;
+    const float r2 = r1 - (float)mk;
+    h[k] = hk;
+    m[k] = mk;
+    l[k] = (__bf16)r2;
+  }
+}
+#endif
 
 #define QEA_WAVE 64
 
@@ -60,5 +79,7 @@ __device__ __forceinline__ float qea_wave_max(float v) {
 }
 
 // event-bracketed timing of one kernel class (bench.py roofline leg)
+// QEA_MFMA=f32 keeps every product on v_mfma_f32_32x32x2_f32; anything else (default) allows the split-bf16 kernels
+bool qea_split_bf16_enabled();
 void qea_prof_begin(int klass, hipStream_t s);
 void qea_prof_end(int klass, hipStream_t s, double flops, double bytes);

@@ -261,22 +261,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvAr
 // fp32-equivalent ceiling against 154 for v_mfma_f32_32x32x2_f32.  One K stage = 16 channels of one tap = one MFMA
 // k-step; LDS holds [plane][row][16 bf16 + 8 pad] (48-byte rows: conflict-free ds_read_b128).
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const __bf16 hk = (__bf16)v[k];
-    const float r1 = v[k] - (float)hk;
-    const __bf16 mk = (__bf16)r1;
-    const float r2 = r1 - (float)mk;
-    h[k] = hk;
-    m[k] = mk;
-    l[k] = (__bf16)r2;
-  }
-}
-
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const ConvArgs p) {
   constexpr int BK = 16;
@@ -357,7 +341,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const Co
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       bf16x4 h, m, l;
-      split3(a_reg[i], h, m, l);
+      qea_split3(a_reg[i], h, m, l);
       const int o = (lrow + RPP * i) * ROWB + kc * 4;
       *reinterpret_cast<bf16x4*>(a_dst + o) = h;
       *reinterpret_cast<bf16x4*>(a_dst + BM * ROWB + o) = m;
@@ -366,7 +350,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const Co
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       bf16x4 h, m, l;
-      split3(b_reg[j], h, m, l);
+      qea_split3(b_reg[j], h, m, l);
       const int o = (lrow + RPP * j) * ROWB + kc * 4;
       *reinterpret_cast<bf16x4*>(b_dst + o) = h;
       *reinterpret_cast<bf16x4*>(b_dst + BN * ROWB + o) = m;
@@ -602,15 +586,6 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
   return QEA_OK;
 }
 
-// QEA_MFMA=f32 keeps every product on v_mfma_f32_32x32x2_f32; anything else (default) allows the split-bf16 tiles
-bool split_bf16_enabled() {
-  static const int on = [] {
-    const char* e = getenv("QEA_MFMA");
-    return (e && strcmp(e, "f32") == 0) ? 0 : 1;
-  }();
-  return on != 0;
-}
-
 bool halo_eligible(const qea_conv_desc* d) {
   const bool ch = (d->Cin == 32 || d->Cin == 64) && (d->N == 32 || d->N == 64);
   const int th = d->Cin == 32 ? 8 : 4;
@@ -671,10 +646,10 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     const long long tiles22 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);
     if (halo_eligible(d)) tile = 4;
     else if (d->N <= 32) tile = 3;
-    else if (split_bf16_enabled() && d->N <= 64) tile = 23;
-    else if (split_bf16_enabled() && d->N % 256 == 0 && tiles22 >= 256) tile = 22;
-    else if (split_bf16_enabled() && tiles21 >= 256) tile = 21;
-    else if (split_bf16_enabled()) tile = 20;
+    else if (qea_split_bf16_enabled() && d->N <= 64) tile = 23;
+    else if (qea_split_bf16_enabled() && d->N % 256 == 0 && tiles22 >= 256) tile = 22;
+    else if (qea_split_bf16_enabled() && tiles21 >= 256) tile = 21;
+    else if (qea_split_bf16_enabled()) tile = 20;
     else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep)
     else if (d->N % 256 == 0 && tiles8 >= 1024) tile = 8;
     else if (tiles7 >= 512) tile = 7;

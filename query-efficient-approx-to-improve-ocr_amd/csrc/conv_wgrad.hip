@@ -244,6 +244,192 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 form of the kernel above (tiles 20-22): P and Q are split into three bf16 planes while they are
+// staged (x = h + m + l, qea_split3) and every product is formed by six v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation.  The LDS planes keep the natural [pixel][channel] order; the MFMA operands (32 channels x 16 pixels,
+// 8 consecutive pixels per lane) come out of them through the gfx950 transposing read ds_read_b64_tr_b16: a 16-lane
+// group reads a 4-pixel x 16-channel block and lane i receives channel i of the 4 pixels, two reads per operand.
+// Row stride = channels*2 + 64 bytes: the four pixel rows of a read fall on four different 64-byte bank ranges.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int row_stride) {
+  // base: element address of (pixel 0 of this lane's 4-pixel block, this lane's 4-channel chunk); second block 4 pixels further
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + 4 * row_stride));
+  // whole-vector reinterpretation (an element-by-element bit_cast of the result was folded into a splat of element 0)
+  return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int BR, int BC, int WR, int WC>
+__global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
+  constexpr int BKP = 16;
+  constexpr int TR = BR / WR, TCc = BC / WC;
+  constexpr int MI = TR / 32, NJ = TCc / 32;
+  constexpr int TPR = 256 / BKP;
+  constexpr int P_LD = BR / (4 * TPR), Q_LD = BC / (4 * TPR);
+  constexpr int PR = BR + 32, QR = BC + 32;  // LDS row strides in bf16 elements (+64 bytes)
+  static_assert(WR * WC == 4 && P_LD >= 1 && Q_LD >= 1, "4 waves, at least one chunk per thread");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* Ps = reinterpret_cast<__bf16*>(smem);  // [2][3][BKP][PR]
+  __bf16* Qs = Ps + 2 * 3 * BKP * PR;            // [2][3][BKP][QR]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int vid = qea_xcd_swizzle(blockIdx.x, a.tiles * a.splits);
+  const int split = vid / a.tiles;
+  const int tile = vid - split * a.tiles;
+  const int taps = a.KH * a.KW;
+  const int c_tile = tile % a.c_tiles;
+  const int tap = (tile / a.c_tiles) % taps;
+  const int r_tile = tile / (a.c_tiles * taps);
+  const int r0 = r_tile * BR, c0 = c_tile * BC;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int m_begin = split * a.chunk;
+  const int m_end = min(a.M, m_begin + a.chunk);
+  const int phw = a.PH * a.PW;
+
+  // gather state: as in wgrad_kernel (one pixel per thread, advanced by BKP per stage)
+  const int grow = tid / TPR, gl = tid % TPR;
+  const int qhw = a.QH * a.QW;
+  const int dq = BKP / a.PW, dr = BKP - dq * a.PW;
+  const int eq = dq / a.PH, er = dq - eq * a.PH;
+  int g_img, g_ph, g_pw;
+  {
+    const int m = m_begin + grow;
+    const int b = m / phw;
+    const int rem = m - b * phw;
+    g_ph = rem / a.PW;
+    g_pw = rem - g_ph * a.PW;
+    g_img = b * qhw;
+  }
+  unsigned colp_ok = 0, colq_ok = 0;
+#pragma unroll
+  for (int i = 0; i < P_LD; ++i) colp_ok |= (unsigned)(r0 + (gl + i * TPR) * 4 < a.R) << i;
+#pragma unroll
+  for (int i = 0; i < Q_LD; ++i) colq_ok |= (unsigned)(c0 + (gl + i * TPR) * 4 < a.C) << i;
+  const float* p_ptr = a.p + (size_t)(m_begin + grow) * a.ldp + r0 + gl * 4;
+  const float* q_col = a.q + c0 + gl * 4;
+
+  f32x4 p_reg[P_LD], q_reg[Q_LD];
+  unsigned p_ok = 0, q_ok = 0;
+  auto gather = [&](int mbase) {
+    const bool row_ok = mbase + grow < m_end;
+    const int qh = g_ph * a.stride_h + kh - a.pad_h;
+    const int qw = g_pw * a.stride_w + kw - a.pad_w;
+    const bool pix_ok = row_ok && (unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW;
+    const float* q_ptr = q_col + (size_t)(pix_ok ? g_img + qh * a.QW + qw : 0) * a.ldq;
+    p_ok = row_ok ? colp_ok : 0u;
+    q_ok = pix_ok ? colq_ok : 0u;
+#pragma unroll
+    for (int i = 0; i < P_LD; ++i) p_reg[i] = *reinterpret_cast<const f32x4*>(((p_ok >> i) & 1) ? p_ptr + i * TPR * 4 : a.p);
+#pragma unroll
+    for (int i = 0; i < Q_LD; ++i) q_reg[i] = *reinterpret_cast<const f32x4*>(((q_ok >> i) & 1) ? q_ptr + i * TPR * 4 : a.q);
+    p_ptr += (size_t)BKP * a.ldp;
+    int pw = g_pw + dr, ph = g_ph + er, img = g_img + eq * qhw;
+    const bool cw = pw >= a.PW;
+    pw -= cw ? a.PW : 0;
+    ph += cw ? 1 : 0;
+    const bool chh = ph >= a.PH;
+    ph -= chh ? a.PH : 0;
+    img += chh ? qhw : 0;
+    g_pw = pw;
+    g_ph = ph;
+    g_img = img;
+  };
+  auto stage = [&](int buf) {
+    __bf16* pd = Ps + (size_t)buf * 3 * BKP * PR + grow * PR + gl * 4;
+    __bf16* qd = Qs + (size_t)buf * 3 * BKP * QR + grow * QR + gl * 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < P_LD; ++i) {
+      bf16x4 h, m, l;
+      qea_split3(((p_ok >> i) & 1) ? p_reg[i] : zero, h, m, l);
+      *reinterpret_cast<bf16x4*>(pd + i * TPR * 4) = h;
+      *reinterpret_cast<bf16x4*>(pd + BKP * PR + i * TPR * 4) = m;
+      *reinterpret_cast<bf16x4*>(pd + 2 * BKP * PR + i * TPR * 4) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < Q_LD; ++i) {
+      bf16x4 h, m, l;
+      qea_split3(((q_ok >> i) & 1) ? q_reg[i] : zero, h, m, l);
+      *reinterpret_cast<bf16x4*>(qd + i * TPR * 4) = h;
+      *reinterpret_cast<bf16x4*>(qd + BKP * QR + i * TPR * 4) = m;
+      *reinterpret_cast<bf16x4*>(qd + 2 * BKP * QR + i * TPR * 4) = l;
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // this lane's place in the transposing reads: 16-lane group g16 -> channels (g16&1)*16.., pixels (g16>>1)*8..;
+  // inside the group lane 4q+pp addresses pixel q, channel chunk pp
+  const int g16 = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
+  const int t_off_p = ((g16 >> 1) * 8 + tq) * PR + wr * TR + (g16 & 1) * 16 + tpp * 4;
+  const int t_off_q = ((g16 >> 1) * 8 + tq) * QR + wc * TCc + (g16 & 1) * 16 + tpp * 4;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nstage = (m_end > m_begin) ? (m_end - m_begin + BKP - 1) / BKP : 0;
+
+  if (nstage > 0) {
+    gather(m_begin);
+    stage(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nstage) gather(m_begin + (st + 1) * BKP);
+    const __bf16* ps = Ps + (size_t)cur * 3 * BKP * PR + t_off_p;
+    const __bf16* qs = Qs + (size_t)cur * 3 * BKP * QR + t_off_q;
+    bf16x8 af[3][MI], bf[3][NJ];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[pl][i] = tr_frag(ps + pl * BKP * PR + i * 32, PR);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[pl][j] = tr_frag(qs + pl * BKP * QR + j * 32, QR);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+      }
+    if (st + 1 < nstage) stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* outp = a.out + (size_t)split * a.slab;
+  const int ktot = taps * a.C;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = r0 + wr * TR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int cc = c0 + wc * TCc + j * 32 + fr;
+        if (rr < a.R && cc < a.C) {
+          const size_t o = (size_t)rr * ktot + tap * a.C + cc;
+          float v = acc[i][j][r];
+          if (a.accumulate) v += outp[o];
+          outp[o] = v;
+        }
+      }
+}
+
 // out[g][i] = sum_{k in group g} ws[k][i]   (float4 elements; group g = blockIdx.y covers `gs` slabs).
 // With gridDim.y == 1 and gs >= splits this is the plain final reduction into dW.
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n4, int splits, int gs,
@@ -296,10 +482,12 @@ Plan make_plan(const qea_wgrad_desc* d) {
   const int R = d->R, C = d->C;
   int tile = d->tile;
   if (tile == 0) {
-    // 16-pixel stages (tiles 9-11): half the LDS of the 32-pixel ones, more resident workgroups, +3-5 % (MI355X)
-    if (R >= 128 && C >= 128) tile = 9;
-    else if (R >= 128 && C == 64) tile = 10;
-    else if (R == 64 && C >= 128) tile = 11;
+    // 16-pixel stages (tiles 9-11): half the LDS of the 32-pixel ones, more resident workgroups, +3-5 % (MI355X);
+    // tiles 20-22 are their split-bf16 forms (default unless QEA_MFMA=f32)
+    const bool bf3 = qea_split_bf16_enabled();
+    if (R >= 128 && C >= 128) tile = bf3 ? 20 : 9;
+    else if (R >= 128 && C == 64) tile = bf3 ? 21 : 10;
+    else if (R == 64 && C >= 128) tile = bf3 ? 22 : 11;
     else if (R <= 32 && C <= 32) tile = 3;
     else if (R <= 32) tile = 4;
     else if (C <= 32) tile = 5;
@@ -311,9 +499,9 @@ Plan make_plan(const qea_wgrad_desc* d) {
     case 2: p.br = 64; p.bc = 64; break;
     case 3: p.br = 32; p.bc = 32; break;
     case 4: p.br = 32; p.bc = 64; break;
-    case 7: case 10: p.br = 128; p.bc = 64; break;
-    case 8: case 11: p.br = 64; p.bc = 128; break;
-    case 9: p.br = 128; p.bc = 128; break;
+    case 7: case 10: case 21: p.br = 128; p.bc = 64; break;
+    case 8: case 11: case 22: p.br = 64; p.bc = 128; break;
+    case 9: case 20: p.br = 128; p.bc = 128; break;
     default: p.br = 64; p.bc = 32; break;
   }
   p.r_tiles = qea_cdiv(R, p.br);
@@ -376,8 +564,45 @@ int slots_of() {
   return slots;
 }
 
+template <int BR, int BC>
+constexpr size_t lds_bytes_bf3() {
+  return (size_t)2 * 3 * 16 * ((BR + 32) + (BC + 32)) * 2;
+}
+
+template <int BR, int BC, int WR, int WC>
+void launch_bf3(const WgArgs& a, hipStream_t s) {
+  constexpr size_t lds = lds_bytes_bf3<BR, BC>();
+  auto kern = wgrad_bf3_kernel<BR, BC, WR, WC>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles * (unsigned)a.splits), dim3(256), lds, s, a);
+}
+
+template <int BR, int BC, int WR, int WC>
+int slots_of_bf3() {
+  static int slots = 0;
+  if (slots == 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    constexpr size_t lds = lds_bytes_bf3<BR, BC>();
+    auto kern = wgrad_bf3_kernel<BR, BC, WR, WC>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 256;
+    (void)hipGetLastError();
+    slots = per_cu * cus;
+  }
+  return slots;
+}
+
 int tile_slots(int tile) {
   switch (tile) {
+    case 20: return slots_of_bf3<128, 128, 2, 2>();
+    case 21: return slots_of_bf3<128, 64, 2, 2>();
+    case 22: return slots_of_bf3<64, 128, 2, 2>();
     case 1: return slots_of<128, 128, 2, 2, 1>();
     case 2: return slots_of<64, 64, 1, 1, 4>();
     case 3: return slots_of<32, 32, 1, 1, 4>();
@@ -614,6 +839,9 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     case 9: launch<128, 128, 2, 2, 1, 16>(a, s); break;   // 16-pixel stages: half the LDS per workgroup
     case 10: launch<128, 64, 2, 2, 1, 16>(a, s); break;
     case 11: launch<64, 128, 2, 2, 1, 16>(a, s); break;
+    case 20: launch_bf3<128, 128, 2, 2>(a, s); break;      // split-bf16 forms
+    case 21: launch_bf3<128, 64, 2, 2>(a, s); break;
+    case 22: launch_bf3<64, 128, 2, 2>(a, s); break;
     default: qea_set_error("qea_conv_wgrad: unknown tile %d", p.tile); return QEA_ERR_INVALID;
   }
   if (p.splits > 1) reduce_slabs((float*)d->workspace, d->dw, a.slab / 4, p.splits, d->accumulate, s);

@@ -1,6 +1,8 @@
 // Library-wide state: last-error string, ABI version, per-kernel-class event timing.
 #include "common.h"
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include <vector>
 
@@ -24,6 +26,14 @@ void qea_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+bool qea_split_bf16_enabled() {
+  static const int on = [] {
+    const char* e = getenv("QEA_MFMA");
+    return (e && strcmp(e, "f32") == 0) ? 0 : 1;
+  }();
+  return on != 0;
 }
 
 extern "C" const char* qea_last_error(void) { return g_err; }

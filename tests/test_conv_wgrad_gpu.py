@@ -34,7 +34,7 @@ def test_wgrad_conv3x3(H, W, Cin, Cout):
     _conv_case(2, H, W, Cin, Cout)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 20, 21, 22])
 def test_wgrad_tiles_ragged_and_splits(tile):
     _conv_case(3, 5, 7, 36, 44, tile=tile, splits=1)
     _conv_case(3, 5, 7, 36, 44, tile=tile, splits=3, accumulate=True)
