@@ -644,13 +644,14 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     // 160-186 TFLOP/s against 110-134, and closer to the fp64 result than the fp32 instruction (fewer accumulator roundings)
     const long long tiles21 = (long long)qea_cdiv(a.M, 256) * qea_cdiv(d->N, 128);
     const long long tiles22 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);
+    // (short-K launches — the transposed convs — are bound by their output traffic, and N < 128 wastes the tile)
+    const bool bf3 = qea_split_bf16_enabled() && d->N >= 128 && a.K >= 256;
     if (halo_eligible(d)) tile = 4;
     else if (d->N <= 32) tile = 3;
-    else if (qea_split_bf16_enabled() && d->N <= 64) tile = 23;
-    else if (qea_split_bf16_enabled() && d->N % 256 == 0 && tiles22 >= 256) tile = 22;
-    else if (qea_split_bf16_enabled() && tiles21 >= 256) tile = 21;
-    else if (qea_split_bf16_enabled()) tile = 20;
-    else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep)
+    else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep; the split-bf16 256x64 tile is slower here)
+    else if (bf3 && d->N % 256 == 0 && tiles22 >= 256) tile = 22;
+    else if (bf3 && tiles21 >= 256) tile = 21;
+    else if (bf3) tile = 20;
     else if (d->N % 256 == 0 && tiles8 >= 1024) tile = 8;
     else if (tiles7 >= 512) tile = 7;
     else if (tiles128 >= 2048) tile = 5;
