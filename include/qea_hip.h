@@ -49,6 +49,9 @@ int qea_prof_reset(void);
 int qea_prof_read(int klass, double* ms, double* flops, double* bytes, int64_t* launches);
 /* per-launch view of the same records (in launch order): up to `capacity` entries, *count = recorded launches */
 int qea_prof_read_launches(int klass, double* ms, double* flops, int64_t capacity, int64_t* count);
+/* The part of a class's algorithmic flops that ran through the split-bf16 kernels (six bf16 MFMAs per fp32
+ * multiply-add): bench.py blends the fp32 and the bf16/6 matrix peaks with it. */
+int qea_prof_read_split_bf16(int klass, double* flops);
 
 /* ------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).

@@ -683,7 +683,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   if (rc != QEA_OK) return rc;
   // algorithmic bytes: input once + filter once + output once
   const double abytes = 4.0 * ((double)d->B * d->H * d->W * d->Cin + (double)d->N * a.K + (double)a.M * d->N);
-  qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes);
+  qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

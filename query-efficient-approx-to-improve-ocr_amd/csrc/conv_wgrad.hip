@@ -845,7 +845,7 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     default: qea_set_error("qea_conv_wgrad: unknown tile %d", p.tile); return QEA_ERR_INVALID;
   }
   if (p.splits > 1) reduce_slabs((float*)d->workspace, d->dw, a.slab / 4, p.splits, d->accumulate, s);
-  qea_prof_end(QEA_PROF_CONV_WGRAD, s, 2.0 * a.M * (double)a.slab, 0.0);
+  qea_prof_end(QEA_PROF_CONV_WGRAD, s, 2.0 * a.M * (double)a.slab, 0.0, p.tile >= 20);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

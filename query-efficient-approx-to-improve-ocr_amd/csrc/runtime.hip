@@ -13,7 +13,7 @@ struct ProfClass {
   bool on = false;
   std::vector<hipEvent_t> start, stop;  // event pool, reused across resets
   size_t used = 0;
-  double flops = 0.0, bytes = 0.0;
+  double flops = 0.0, bytes = 0.0, flops_split = 0.0;  // flops_split: the part that ran as split-bf16 MFMAs
   std::vector<double> launch_flops;
   bool open = false;
 };
@@ -53,7 +53,7 @@ void qea_prof_begin(int klass, hipStream_t s) {
   pc.open = true;
 }
 
-void qea_prof_end(int klass, hipStream_t s, double flops, double bytes) {
+void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool split_bf16) {
   ProfClass& pc = g_prof[klass];
   if (!pc.on || !pc.open) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -62,6 +62,7 @@ void qea_prof_end(int klass, hipStream_t s, double flops, double bytes) {
   pc.launch_flops.push_back(flops);
   pc.flops += flops;
   pc.bytes += bytes;
+  if (split_bf16) pc.flops_split += flops;
   pc.open = false;
 }
 
@@ -76,7 +77,7 @@ extern "C" int qea_prof_reset(void) {
   for (auto& pc : g_prof) {
     pc.used = 0;
     pc.launch_flops.clear();
-    pc.flops = pc.bytes = 0.0;
+    pc.flops = pc.bytes = pc.flops_split = 0.0;
     pc.open = false;
   }
   return QEA_OK;
@@ -100,6 +101,13 @@ extern "C" int qea_prof_read(int klass, double* ms, double* flops, double* bytes
   if (flops) *flops = pc.flops;
   if (bytes) *bytes = pc.bytes;
   if (launches) *launches = (int64_t)pc.used;
+  return QEA_OK;
+}
+
+extern "C" int qea_prof_read_split_bf16(int klass, double* flops) {
+  QEA_REQUIRE(klass >= 0 && klass < QEA_PROF_NCLASS && flops, "qea_prof_read_split_bf16: bad arguments");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  *flops = g_prof[klass].flops_split;
   return QEA_OK;
 }
 

@@ -129,7 +129,9 @@ def prof_reset():
 def prof_read(klass):
     ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
     _lib.check(_lib.lib().qea_prof_read(klass, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "qea_prof_read")
-    return {"ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value}
+    sp = C.c_double()
+    _lib.check(_lib.lib().qea_prof_read_split_bf16(klass, C.byref(sp)), "qea_prof_read_split_bf16")
+    return {"ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value, "flops_split_bf16": sp.value}
 
 
 # ----------------------------------------------------------------------------- BN / pool / misc

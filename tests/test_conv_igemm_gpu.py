@@ -89,3 +89,34 @@ def test_conv3x3_halo_kernel_strided_buffers(Cin, Cout, H, W):
     got = yb[..., 64:].cpu().permute(0, 3, 1, 2).double()
     assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
     assert (yb[..., :64] == -3.0).all()
+
+
+def test_split_bf16_is_not_reduced_precision():
+    """The split-bf16 kernels (tiles 20-22, x = h+m+l, six bf16 MFMAs per product, fp32 accumulate) against the native
+    fp32-MFMA kernels, both measured against fp64: on a long reduction (forward, K = 9*512) the split form must be at least as
+    close (it rounds the accumulator 16 products at a time instead of 2); on a short one (wgrad over 512 pixels) its floor is
+    the 3-plane representation error of about one fp32 rounding unit (2^-23).  Wide-dynamic-range operands (1e-3 ... 1e3)
+    included, since the split is relative to each element."""
+    ULP = 2.0 ** -23
+    from qea import ops
+    g = torch.Generator().manual_seed(7)
+    B, H, W, Ci, Co = 4, 4, 32, 512, 512
+    for spread in (1.0, 3.0):
+        x = torch.randn(B, H, W, Ci, generator=g) * torch.exp(spread * torch.randn(B, H, W, Ci, generator=g))
+        w = torch.randn(Co, 3, 3, Ci, generator=g) * 0.02 * torch.exp(spread * torch.randn(Co, 3, 3, Ci, generator=g))
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+        errs = {}
+        for tile in (8, 22):
+            y = torch.empty(B, H, W, Co, device="cuda")
+            ops.conv_igemm(x.cuda(), w.cuda(), y, B=B, H=H, W=W, Cin=Ci, OH=H, OW=W, N=Co, KH=3, KW=3, pad=(1, 1), ldx=Ci, ldy=Co, tile=tile)
+            errs[tile] = ((y.cpu().double() - ref).norm() / ref.norm()).item()
+        assert errs[22] <= max(1.25 * errs[8], 2 * ULP), errs
+        dy = torch.randn(B, H, W, Co, generator=g) * torch.exp(spread * torch.randn(B, H, W, Co, generator=g))
+        refw = torch.einsum("bhwo,bhwkc->okc", dy.double(),
+                            F.unfold(x.permute(0, 3, 1, 2).double(), 3, padding=1).view(B, Ci, 9, H, W).permute(0, 3, 4, 2, 1))
+        errs = {}
+        for tile in (9, 20):
+            dw = torch.empty(Co, 3, 3, Ci, device="cuda")
+            ops.conv_wgrad(dy.cuda(), x.cuda(), dw, B=B, PH=H, PW=W, QH=H, QW=W, R=Co, Cc=Ci, KH=3, KW=3, pad=(1, 1), ldp=Co, ldq=Ci, tile=tile)
+            errs[tile] = ((dw.cpu().double().view(Co, 9, Ci) - refw).norm() / refw.norm()).item()
+        assert errs[20] <= max(1.25 * errs[9], 2 * ULP), errs
