@@ -11,8 +11,8 @@ kernels are charged to the wgrad launch they belong to.
 import collections, csv, glob, json, sys
 
 CLASSES = {
-    "conv_igemm": (("conv_igemm_kernel", "conv3x3_halo_kernel"), ()),
-    "conv_wgrad": (("wgrad_kernel", "wgrad_halo_kernel"), ("splitk_reduce_kernel",)),
+    "conv_igemm": (("conv_igemm_kernel", "conv_igemm_bf3_kernel", "conv3x3_halo_kernel"), ()),
+    "conv_wgrad": (("wgrad_kernel", "wgrad_bf3_kernel", "wgrad_halo_kernel"), ("splitk_reduce_kernel",)),
 }
 
 
