@@ -259,13 +259,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvAr
 // (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll terms are < 2^-23 |ab|) accumulated in fp32:
 // v_mfma_f32_32x32x16_bf16 sustains 1800 TFLOP/s on this part (tools/micro/mfma_rate.hip), i.e. a 300 TFLOP/s
 // fp32-equivalent ceiling against 154 for v_mfma_f32_32x32x2_f32.  One K stage = 16 channels of one tap = one MFMA
-// k-step; LDS holds [plane][row][16 bf16 + 8 pad] (48-byte rows: conflict-free ds_read_b128).
+// k-step; LDS holds [plane][row][16 bf16] (32-byte rows, halves of rows 8..15 mod 16 swapped: conflict-free ds_read_b128).
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const ConvArgs p) {
   constexpr int BK = 16;
   constexpr int NT = WGM * WGN * 64;
-  constexpr int ROWB = 24;                     // bf16 elements per LDS row (16 + 8 pad = 48 bytes)
+  constexpr int ROWB = 16;                     // bf16 elements per LDS row: 32 bytes, unpadded; the two 16-byte halves of rows
+                                               // 8..15 (mod 16) are swapped, which keeps ds_read_b128 conflict-free (see frag)
   constexpr int KCH = BK / 4;                  // float4 per row of a K-slice
   constexpr int RPP = NT / KCH;                // rows covered per pass of the workgroup's threads
   constexpr int TM = BM / WGM, TN = BN / WGN;  // wave tile
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const Co
     for (int i = 0; i < A_LD; ++i) {
       bf16x4 h, m, l;
       qea_split3(a_reg[i], h, m, l);
-      const int o = (lrow + RPP * i) * ROWB + kc * 4;
+      const int ro = lrow + RPP * i;
+      const int o = ro * ROWB + (((kc >> 1) ^ ((ro >> 3) & 1)) << 3) + (kc & 1) * 4;
       *reinterpret_cast<bf16x4*>(a_dst + o) = h;
       *reinterpret_cast<bf16x4*>(a_dst + BM * ROWB + o) = m;
       *reinterpret_cast<bf16x4*>(a_dst + 2 * BM * ROWB + o) = l;
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const Co
     for (int j = 0; j < B_LD; ++j) {
       bf16x4 h, m, l;
       qea_split3(b_reg[j], h, m, l);
-      const int o = (lrow + RPP * j) * ROWB + kc * 4;
+      const int ro = lrow + RPP * j;
+      const int o = ro * ROWB + (((kc >> 1) ^ ((ro >> 3) & 1)) << 3) + (kc & 1) * 4;
       *reinterpret_cast<bf16x4*>(b_dst + o) = h;
       *reinterpret_cast<bf16x4*>(b_dst + BN * ROWB + o) = m;
       *reinterpret_cast<bf16x4*>(b_dst + 2 * BN * ROWB + o) = l;
@@ -373,8 +376,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const Co
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < KT) gather(kt + 1);
-    const __bf16* a_src = As + (size_t)cur * 3 * BM * ROWB + (wm * TM + fr) * ROWB + fh * 8;
-    const __bf16* b_src = Bs + (size_t)cur * 3 * BN * ROWB + (wn * TN + fr) * ROWB + fh * 8;
+    // lane (fr, fh) reads the 8 k-values of half fh of row fr; rows 8..15 (mod 16) keep their halves swapped
+    const int hsw = (fh ^ ((fr >> 3) & 1)) * 8;   // wm*TM, wn*TN and i*32 are multiples of 16: the swap depends on fr only
+    const __bf16* a_src = As + (size_t)cur * 3 * BM * ROWB + (wm * TM + fr) * ROWB + hsw;
+    const __bf16* b_src = Bs + (size_t)cur * 3 * BN * ROWB + (wn * TN + fr) * ROWB + hsw;
     bf16x8 af[3][MI], bf[3][NJ];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
@@ -407,7 +412,7 @@ int launch_bf3(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.m_tiles = qea_cdiv(p.M, BM);
   p.n_tiles = qea_cdiv(p.N, BN);
-  const size_t lds = (size_t)2 * 3 * (BM + BN) * 24 * 2;
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * 16 * 2;
   auto kern = conv_igemm_bf3_kernel<BM, BN, WGM, WGN>;
   static bool attr_set = false;
   if (!attr_set) {
