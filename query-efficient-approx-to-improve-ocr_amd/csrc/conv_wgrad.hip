@@ -270,7 +270,11 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
   constexpr int MI = TR / 32, NJ = TCc / 32;
   constexpr int TPR = 256 / BKP;
   constexpr int P_LD = BR / (4 * TPR), Q_LD = BC / (4 * TPR);
-  constexpr int PR = BR + 32, QR = BC + 32;  // LDS row strides in bf16 elements (+64 bytes)
+  // LDS rows = pixels.  A transposing read takes 4 consecutive pixels x one 64-byte (32-channel) chunk: with 128+ channels
+  // per row the rows are unpadded and the 64-byte chunks of pixel p are stored at chunk index c ^ (p & 3), so the 4 rows
+  // of a read fall on 4 different bank ranges; 64-channel rows (2 chunks) keep a 64-byte pad instead.
+  constexpr int PR = BR >= 128 ? BR : BR + 32, QR = BC >= 128 ? BC : BC + 32;
+  constexpr bool SWP = BR >= 128, SWQ = BC >= 128;
   static_assert(WR * WC == 4 && P_LD >= 1 && Q_LD >= 1, "4 waves, at least one chunk per thread");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -341,24 +345,28 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
     g_img = img;
   };
   auto stage = [&](int buf) {
-    __bf16* pd = Ps + (size_t)buf * 3 * BKP * PR + grow * PR + gl * 4;
-    __bf16* qd = Qs + (size_t)buf * 3 * BKP * QR + grow * QR + gl * 4;
+    __bf16* pd = Ps + (size_t)buf * 3 * BKP * PR + grow * PR;
+    __bf16* qd = Qs + (size_t)buf * 3 * BKP * QR + grow * QR;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < P_LD; ++i) {
       bf16x4 h, m, l;
       qea_split3(((p_ok >> i) & 1) ? p_reg[i] : zero, h, m, l);
-      *reinterpret_cast<bf16x4*>(pd + i * TPR * 4) = h;
-      *reinterpret_cast<bf16x4*>(pd + BKP * PR + i * TPR * 4) = m;
-      *reinterpret_cast<bf16x4*>(pd + 2 * BKP * PR + i * TPR * 4) = l;
+      const int e0 = (gl + i * TPR) * 4;  // first channel of this chunk
+      const int eo = SWP ? ((((e0 >> 5) ^ (grow & 3)) << 5) | (e0 & 31)) : e0;
+      *reinterpret_cast<bf16x4*>(pd + eo) = h;
+      *reinterpret_cast<bf16x4*>(pd + BKP * PR + eo) = m;
+      *reinterpret_cast<bf16x4*>(pd + 2 * BKP * PR + eo) = l;
     }
 #pragma unroll
     for (int i = 0; i < Q_LD; ++i) {
       bf16x4 h, m, l;
       qea_split3(((q_ok >> i) & 1) ? q_reg[i] : zero, h, m, l);
-      *reinterpret_cast<bf16x4*>(qd + i * TPR * 4) = h;
-      *reinterpret_cast<bf16x4*>(qd + BKP * QR + i * TPR * 4) = m;
-      *reinterpret_cast<bf16x4*>(qd + 2 * BKP * QR + i * TPR * 4) = l;
+      const int e0 = (gl + i * TPR) * 4;
+      const int eo = SWQ ? ((((e0 >> 5) ^ (grow & 3)) << 5) | (e0 & 31)) : e0;
+      *reinterpret_cast<bf16x4*>(qd + eo) = h;
+      *reinterpret_cast<bf16x4*>(qd + BKP * QR + eo) = m;
+      *reinterpret_cast<bf16x4*>(qd + 2 * BKP * QR + eo) = l;
     }
   };
 
@@ -373,8 +381,9 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
   // this lane's place in the transposing reads: 16-lane group g16 -> channels (g16&1)*16.., pixels (g16>>1)*8..;
   // inside the group lane 4q+pp addresses pixel q, channel chunk pp
   const int g16 = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
-  const int t_off_p = ((g16 >> 1) * 8 + tq) * PR + wr * TR + (g16 & 1) * 16 + tpp * 4;
-  const int t_off_q = ((g16 >> 1) * 8 + tq) * QR + wc * TCc + (g16 & 1) * 16 + tpp * 4;
+  // (pixel & 3) of both 4-pixel blocks of a lane is tq: the chunk swizzle of a read is the same for its two halves
+  const int t_row_p = ((g16 >> 1) * 8 + tq) * PR, t_row_q = ((g16 >> 1) * 8 + tq) * QR;
+  const int t_col = (g16 & 1) * 16 + tpp * 4;  // inside the 32-channel chunk
   const int fr = lane & 31, fh = lane >> 5;
   const int nstage = (m_end > m_begin) ? (m_end - m_begin + BKP - 1) / BKP : 0;
 
@@ -386,15 +395,21 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
   for (int st = 0; st < nstage; ++st) {
     const int cur = st & 1;
     if (st + 1 < nstage) gather(m_begin + (st + 1) * BKP);
-    const __bf16* ps = Ps + (size_t)cur * 3 * BKP * PR + t_off_p;
-    const __bf16* qs = Qs + (size_t)cur * 3 * BKP * QR + t_off_q;
+    const __bf16* ps = Ps + (size_t)cur * 3 * BKP * PR + t_row_p + t_col;
+    const __bf16* qs = Qs + (size_t)cur * 3 * BKP * QR + t_row_q + t_col;
     bf16x8 af[3][MI], bf[3][NJ];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[pl][i] = tr_frag(ps + pl * BKP * PR + i * 32, PR);
+      for (int i = 0; i < MI; ++i) {
+        const int ch = (wr * TR) / 32 + i;  // 32-channel chunk of this tile
+        af[pl][i] = tr_frag(ps + pl * BKP * PR + ((SWP ? (ch ^ tq) : ch) << 5), PR);
+      }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[pl][j] = tr_frag(qs + pl * BKP * QR + j * 32, QR);
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = (wc * TCc) / 32 + j;
+        bf[pl][j] = tr_frag(qs + pl * BKP * QR + ((SWQ ? (ch ^ tq) : ch) << 5), QR);
+      }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -566,7 +581,7 @@ int slots_of() {
 
 template <int BR, int BC>
 constexpr size_t lds_bytes_bf3() {
-  return (size_t)2 * 3 * 16 * ((BR + 32) + (BC + 32)) * 2;
+  return (size_t)2 * 3 * 16 * ((BR >= 128 ? BR : BR + 32) + (BC >= 128 ? BC : BC + 32)) * 2;
 }
 
 template <int BR, int BC, int WR, int WC>
