@@ -651,7 +651,10 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     const long long tiles22 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);
     // (short-K launches — the transposed convs — are bound by their output traffic, and N < 128 wastes the tile)
     const bool bf3 = qea_split_bf16_enabled() && d->N >= 128 && a.K >= 256;
-    if (halo_eligible(d)) tile = 4;
+    // 33..64 output channels: the split-bf16 256x64 tile beats both the fp32 256x64 tile (132 vs 107 TFLOP/s at Cin = 128) and
+    // the fp32 LDS-halo kernel at Cin = 64 (120 vs 111); the halo kernel keeps Cin = 32 (K = 288: 102 vs 91)
+    if (qea_split_bf16_enabled() && d->N > 32 && d->N <= 64 && a.K >= 256 && d->Cin >= 64) tile = 23;
+    else if (halo_eligible(d)) tile = 4;
     else if (d->N <= 32) tile = 3;
     else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep; the split-bf16 256x64 tile is slower here)
     else if (bf3 && d->N % 256 == 0 && tiles22 >= 256) tile = 22;
