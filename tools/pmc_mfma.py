@@ -7,13 +7,13 @@
 mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (CUs * 4 SIMDs * shader cycles), shader cycles = GRBM_GUI_ACTIVE / 8 (the counter
 is summed over the 8 XCDs); clock_ghz = shader cycles / kernel duration.  Time-weighted means over the launches of a kernel.
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 CUS = 256
 
 
 def main():
-    f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     seen = set()
     for r in csv.DictReader(open(f)):

@@ -8,7 +8,7 @@ Both counters are reported in KiB; FETCH_SIZE is doubled on gfx950 (MI355X_MICRO
 coalesced reads are tallied at 64 B).  A "launch" is one qea_conv_igemm / qea_conv_wgrad call, i.e. the split-K reduction
 kernels are charged to the wgrad launch they belong to.
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 CLASSES = {
     "conv_igemm": (("conv_igemm_kernel", "conv_igemm_bf3_kernel", "conv3x3_halo_kernel"), ()),
@@ -17,7 +17,7 @@ CLASSES = {
 
 
 def totals(d, counter):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     tot, n = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
