@@ -54,7 +54,11 @@ int qea_prof_read_launches(int klass, double* ms, double* flops, int64_t capacit
 int qea_prof_read_split_bf16(int klass, double* flops);
 
 /* ------------------------------------------------------------------------------------
- * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ * Implicit-GEMM convolution on the matrix cores with fp32-class accuracy: v_mfma_f32_32x32x2_f32, or — by default
+ * for N >= 64-128 output channels and K >= 256 (tiles 20-23) — the split-bf16 form: fp32 operands split on the fly into
+ * three bf16 values x = h + m + l, six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation (at least as close to
+ * the fp64 result as the fp32 instruction on long reductions).  QEA_MFMA=f32 in the environment keeps every launch on
+ * the fp32 instruction.
  *   y[b,oh,ow,n] = epilogue( sum_{kh,kw,c} x[b, oh*sh+kh-ph, ow*sw+kw-pw, c] * w[n,kh,kw,c] )
  * Replaces nn.Conv2d forward at models/model_unet.py:78-109 (3x3 p1, bias=False),
  * models/model_crnn.py:38-45,49-55 (3x3 p1 and the 2x2 p0 conv7); run on
@@ -91,8 +95,8 @@ typedef struct qea_conv_desc {
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Weight gradient on the fp32 matrix cores (reduction over pixels, split over blocks,
- * order-fixed second pass: bit-reproducible).
+ * Weight gradient on the matrix cores (fp32 MFMA, or the split-bf16 form of qea_conv_igemm for R, C >= 64 with one
+ * of them >= 128: tiles 20-22); reduction over pixels, split over blocks, order-fixed second pass: bit-reproducible.
  *   dw[r][kh][kw][c] (+)= sum_{b,ph,pw} p[b,ph,pw][r] * q[b, ph*sh+kh-pad_h, pw*sw+kw-pad_w][c]
  * nn.Conv2d weight gradient (autograd of models/model_unet.py:78-109, model_crnn.py:38-45):
  *   p = dY, q = X.  nn.ConvTranspose2d (model_unet.py:25-41): p = X, q = dY, KH=KW=2,
