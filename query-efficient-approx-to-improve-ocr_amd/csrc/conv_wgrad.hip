@@ -30,7 +30,79 @@ struct WgArgs {
   long long slab;               // floats per split slab (R*taps*C)
 };
 
-constexpr int BKP_MAX = 32;  // pixels per stage (split chunks are rounded to this)
+constexpr int BKP_MAX = 32;
+
+// Per-thread operand fetch shared by the fp32 and the split-bf16 kernel.  The 256 threads cover the BKP pixel rows of a
+// stage with TPR threads per row; a thread keeps ONE pixel row and loads P_LD float4 chunks of P and Q_LD of Q from it
+// (chunk gl + i*TPR), so a single pixel -> (image, row, column) split serves all its loads.  The split is done once and
+// then advanced by BKP pixels per stage with two conditional carries: no divisions and no branches inside the main loop
+// (out-of-range slots load from a safe address; p_ok / q_ok tell the staging code which slots to zero).
+template <int P_LD, int Q_LD, int BKP>
+struct WgGather {
+  static constexpr int TPR = 256 / BKP;
+  int grow, gl;
+  int g_img, g_ph, g_pw;       // image offset (pixels of q), output row / column of this thread's current pixel
+  int qhw, dr, er, eq;         // BKP pixels = eq images + er rows + dr columns
+  int kh, kw, m_end;
+  unsigned colp_ok, colq_ok;   // bit i: chunk i of this thread lies inside R (C)
+  unsigned p_ok, q_ok;         // bit i: slot i holds real data
+  const float* p_ptr;
+  const float* q_col;
+  f32x4 p_reg[P_LD], q_reg[Q_LD];
+
+  __device__ __forceinline__ void init(const WgArgs& a, int tid, int m_begin, int m_end_, int r0, int c0, int kh_, int kw_) {
+    grow = tid / TPR;
+    gl = tid % TPR;
+    kh = kh_;
+    kw = kw_;
+    m_end = m_end_;
+    qhw = a.QH * a.QW;
+    const int dq = BKP / a.PW;
+    dr = BKP - dq * a.PW;
+    eq = dq / a.PH;
+    er = dq - eq * a.PH;
+    const int phw = a.PH * a.PW;
+    const int m = m_begin + grow;
+    const int b = m / phw;
+    const int rem = m - b * phw;
+    g_ph = rem / a.PW;
+    g_pw = rem - g_ph * a.PW;
+    g_img = b * qhw;
+    colp_ok = colq_ok = p_ok = q_ok = 0;
+#pragma unroll
+    for (int i = 0; i < P_LD; ++i) colp_ok |= (unsigned)(r0 + (gl + i * TPR) * 4 < a.R) << i;
+#pragma unroll
+    for (int i = 0; i < Q_LD; ++i) colq_ok |= (unsigned)(c0 + (gl + i * TPR) * 4 < a.C) << i;
+    p_ptr = a.p + (size_t)(m_begin + grow) * a.ldp + r0 + gl * 4;
+    q_col = a.q + c0 + gl * 4;
+  }
+
+  // issue the loads of the stage that starts at pixel mbase, then advance the pixel by BKP
+  __device__ __forceinline__ void fetch(const WgArgs& a, int mbase) {
+    const bool row_ok = mbase + grow < m_end;
+    const int qh = g_ph * a.stride_h + kh - a.pad_h;
+    const int qw = g_pw * a.stride_w + kw - a.pad_w;
+    const bool pix_ok = row_ok && (unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW;
+    const float* q_ptr = q_col + (size_t)(pix_ok ? g_img + qh * a.QW + qw : 0) * a.ldq;
+    p_ok = row_ok ? colp_ok : 0u;
+    q_ok = pix_ok ? colq_ok : 0u;
+#pragma unroll
+    for (int i = 0; i < P_LD; ++i) p_reg[i] = *reinterpret_cast<const f32x4*>(((p_ok >> i) & 1) ? p_ptr + i * TPR * 4 : a.p);
+#pragma unroll
+    for (int i = 0; i < Q_LD; ++i) q_reg[i] = *reinterpret_cast<const f32x4*>(((q_ok >> i) & 1) ? q_ptr + i * TPR * 4 : a.q);
+    p_ptr += (size_t)BKP * a.ldp;
+    int pw = g_pw + dr, ph = g_ph + er, img = g_img + eq * qhw;
+    const bool cw = pw >= a.PW;
+    pw -= cw ? a.PW : 0;
+    ph += cw ? 1 : 0;
+    const bool chh = ph >= a.PH;
+    ph -= chh ? a.PH : 0;
+    img += chh ? qhw : 0;
+    g_pw = pw;
+    g_ph = ph;
+    g_img = img;
+  }
+};  // pixels per stage (split chunks are rounded to this)
 
 template <int BR, int BC, int WR, int WC, int WK, int BKP = 32>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
@@ -68,71 +140,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
 
   const int m_begin = split * a.chunk;
   const int m_end = min(a.M, m_begin + a.chunk);
-  const int phw = a.PH * a.PW;
 
-  // ---- gather state.  The 256 threads cover the BKP pixel rows of a stage with TPR threads per row; a thread
-  // keeps ONE pixel row and loads P_LD float4 chunks of P and Q_LD of Q from it (chunk l + i*TPR), so a single
-  // pixel -> (image, row, column) split serves all its loads.  The split is done once and then advanced by BKP
-  // pixels per stage with two conditional carries: no divisions and no branches inside the main loop
-  // (out-of-range slots load from a safe address and are zeroed by a select).
   constexpr int TPR = 256 / BKP;
   static_assert(P_LD * TPR * 4 == BR && Q_LD * TPR * 4 == BC, "chunks per thread");
-  const int grow = tid / TPR, gl = tid % TPR;
-  const int qhw = a.QH * a.QW;
-  const int dq = BKP / a.PW, dr = BKP - dq * a.PW;  // BKP pixels = dq rows + dr columns
-  const int eq = dq / a.PH, er = dq - eq * a.PH;    //            = eq images + er rows + dr columns
-  int g_img, g_ph, g_pw;
-  {
-    const int m = m_begin + grow;
-    const int b = m / phw;
-    const int rem = m - b * phw;
-    g_ph = rem / a.PW;
-    g_pw = rem - g_ph * a.PW;
-    g_img = b * qhw;
-  }
-  unsigned colp_ok = 0, colq_ok = 0;  // bit i: chunk i of this thread lies inside R (C)
-#pragma unroll
-  for (int i = 0; i < P_LD; ++i) colp_ok |= (unsigned)(r0 + (gl + i * TPR) * 4 < a.R) << i;
-#pragma unroll
-  for (int i = 0; i < Q_LD; ++i) colq_ok |= (unsigned)(c0 + (gl + i * TPR) * 4 < a.C) << i;
-  const float* p_ptr = a.p + (size_t)(m_begin + grow) * a.ldp + r0 + gl * 4;
-  const float* q_col = a.q + c0 + gl * 4;
-
-  f32x4 p_reg[P_LD], q_reg[Q_LD];
-  unsigned p_ok = 0, q_ok = 0;  // bit i: slot i holds real data
-  auto gather = [&](int mbase) {
-    const bool row_ok = mbase + grow < m_end;
-    const int qh = g_ph * a.stride_h + kh - a.pad_h;
-    const int qw = g_pw * a.stride_w + kw - a.pad_w;
-    const bool pix_ok = row_ok && (unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW;
-    const float* q_ptr = q_col + (size_t)(pix_ok ? g_img + qh * a.QW + qw : 0) * a.ldq;
-    p_ok = row_ok ? colp_ok : 0u;
-    q_ok = pix_ok ? colq_ok : 0u;
-#pragma unroll
-    for (int i = 0; i < P_LD; ++i) p_reg[i] = *reinterpret_cast<const f32x4*>(((p_ok >> i) & 1) ? p_ptr + i * TPR * 4 : a.p);
-#pragma unroll
-    for (int i = 0; i < Q_LD; ++i) q_reg[i] = *reinterpret_cast<const f32x4*>(((q_ok >> i) & 1) ? q_ptr + i * TPR * 4 : a.q);
-    p_ptr += (size_t)BKP * a.ldp;
-    // advance the pixel by BKP
-    int pw = g_pw + dr, ph = g_ph + er, img = g_img + eq * qhw;
-    const bool cw = pw >= a.PW;
-    pw -= cw ? a.PW : 0;
-    ph += cw ? 1 : 0;
-    const bool chh = ph >= a.PH;
-    ph -= chh ? a.PH : 0;
-    img += chh ? qhw : 0;
-    g_pw = pw;
-    g_ph = ph;
-    g_img = img;
-  };
+  WgGather<P_LD, Q_LD, BKP> g;
+  g.init(a, tid, m_begin, m_end, r0, c0, kh, kw);
+  auto gather = [&](int mbase) { g.fetch(a, mbase); };
   auto stage = [&](int buf) {
-    float* pd = Ps + buf * BKP * BR + grow * BR + gl * 4;
-    float* qd = Qs + buf * BKP * BC + grow * BC + gl * 4;
+    float* pd = Ps + buf * BKP * BR + g.grow * BR + g.gl * 4;
+    float* qd = Qs + buf * BKP * BC + g.grow * BC + g.gl * 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < P_LD; ++i) *reinterpret_cast<f32x4*>(pd + i * TPR * 4) = ((p_ok >> i) & 1) ? p_reg[i] : zero;
+    for (int i = 0; i < P_LD; ++i) *reinterpret_cast<f32x4*>(pd + i * TPR * 4) = ((g.p_ok >> i) & 1) ? g.p_reg[i] : zero;
 #pragma unroll
-    for (int i = 0; i < Q_LD; ++i) *reinterpret_cast<f32x4*>(qd + i * TPR * 4) = ((q_ok >> i) & 1) ? q_reg[i] : zero;
+    for (int i = 0; i < Q_LD; ++i) *reinterpret_cast<f32x4*>(qd + i * TPR * 4) = ((g.q_ok >> i) & 1) ? g.q_reg[i] : zero;
   };
 
   f32x16 acc[MI][NJ];
@@ -294,66 +315,20 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
   const int kh = tap / a.KW, kw = tap - kh * a.KW;
   const int m_begin = split * a.chunk;
   const int m_end = min(a.M, m_begin + a.chunk);
-  const int phw = a.PH * a.PW;
 
-  // gather state: as in wgrad_kernel (one pixel per thread, advanced by BKP per stage)
-  const int grow = tid / TPR, gl = tid % TPR;
-  const int qhw = a.QH * a.QW;
-  const int dq = BKP / a.PW, dr = BKP - dq * a.PW;
-  const int eq = dq / a.PH, er = dq - eq * a.PH;
-  int g_img, g_ph, g_pw;
-  {
-    const int m = m_begin + grow;
-    const int b = m / phw;
-    const int rem = m - b * phw;
-    g_ph = rem / a.PW;
-    g_pw = rem - g_ph * a.PW;
-    g_img = b * qhw;
-  }
-  unsigned colp_ok = 0, colq_ok = 0;
-#pragma unroll
-  for (int i = 0; i < P_LD; ++i) colp_ok |= (unsigned)(r0 + (gl + i * TPR) * 4 < a.R) << i;
-#pragma unroll
-  for (int i = 0; i < Q_LD; ++i) colq_ok |= (unsigned)(c0 + (gl + i * TPR) * 4 < a.C) << i;
-  const float* p_ptr = a.p + (size_t)(m_begin + grow) * a.ldp + r0 + gl * 4;
-  const float* q_col = a.q + c0 + gl * 4;
-
-  f32x4 p_reg[P_LD], q_reg[Q_LD];
-  unsigned p_ok = 0, q_ok = 0;
-  auto gather = [&](int mbase) {
-    const bool row_ok = mbase + grow < m_end;
-    const int qh = g_ph * a.stride_h + kh - a.pad_h;
-    const int qw = g_pw * a.stride_w + kw - a.pad_w;
-    const bool pix_ok = row_ok && (unsigned)qh < (unsigned)a.QH && (unsigned)qw < (unsigned)a.QW;
-    const float* q_ptr = q_col + (size_t)(pix_ok ? g_img + qh * a.QW + qw : 0) * a.ldq;
-    p_ok = row_ok ? colp_ok : 0u;
-    q_ok = pix_ok ? colq_ok : 0u;
-#pragma unroll
-    for (int i = 0; i < P_LD; ++i) p_reg[i] = *reinterpret_cast<const f32x4*>(((p_ok >> i) & 1) ? p_ptr + i * TPR * 4 : a.p);
-#pragma unroll
-    for (int i = 0; i < Q_LD; ++i) q_reg[i] = *reinterpret_cast<const f32x4*>(((q_ok >> i) & 1) ? q_ptr + i * TPR * 4 : a.q);
-    p_ptr += (size_t)BKP * a.ldp;
-    int pw = g_pw + dr, ph = g_ph + er, img = g_img + eq * qhw;
-    const bool cw = pw >= a.PW;
-    pw -= cw ? a.PW : 0;
-    ph += cw ? 1 : 0;
-    const bool chh = ph >= a.PH;
-    ph -= chh ? a.PH : 0;
-    img += chh ? qhw : 0;
-    g_pw = pw;
-    g_ph = ph;
-    g_img = img;
-  };
+  WgGather<P_LD, Q_LD, BKP> g;
+  g.init(a, tid, m_begin, m_end, r0, c0, kh, kw);
+  auto gather = [&](int mbase) { g.fetch(a, mbase); };
   auto stage = [&](int buf) {
-    __bf16* pd = Ps + (size_t)buf * 3 * BKP * PR + grow * PR;
-    __bf16* qd = Qs + (size_t)buf * 3 * BKP * QR + grow * QR;
+    __bf16* pd = Ps + (size_t)buf * 3 * BKP * PR + g.grow * PR;
+    __bf16* qd = Qs + (size_t)buf * 3 * BKP * QR + g.grow * QR;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < P_LD; ++i) {
       bf16x4 h, m, l;
-      qea_split3(((p_ok >> i) & 1) ? p_reg[i] : zero, h, m, l);
-      const int e0 = (gl + i * TPR) * 4;  // first channel of this chunk
-      const int eo = SWP ? ((((e0 >> 5) ^ (grow & 3)) << 5) | (e0 & 31)) : e0;
+      qea_split3(((g.p_ok >> i) & 1) ? g.p_reg[i] : zero, h, m, l);
+      const int e0 = (g.gl + i * TPR) * 4;  // first channel of this chunk
+      const int eo = SWP ? ((((e0 >> 5) ^ (g.grow & 3)) << 5) | (e0 & 31)) : e0;
       *reinterpret_cast<bf16x4*>(pd + eo) = h;
       *reinterpret_cast<bf16x4*>(pd + BKP * PR + eo) = m;
       *reinterpret_cast<bf16x4*>(pd + 2 * BKP * PR + eo) = l;
@@ -361,9 +336,9 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
 #pragma unroll
     for (int i = 0; i < Q_LD; ++i) {
       bf16x4 h, m, l;
-      qea_split3(((q_ok >> i) & 1) ? q_reg[i] : zero, h, m, l);
-      const int e0 = (gl + i * TPR) * 4;
-      const int eo = SWQ ? ((((e0 >> 5) ^ (grow & 3)) << 5) | (e0 & 31)) : e0;
+      qea_split3(((g.q_ok >> i) & 1) ? g.q_reg[i] : zero, h, m, l);
+      const int e0 = (g.gl + i * TPR) * 4;
+      const int eo = SWQ ? ((((e0 >> 5) ^ (g.grow & 3)) << 5) | (e0 & 31)) : e0;
       *reinterpret_cast<bf16x4*>(qd + eo) = h;
       *reinterpret_cast<bf16x4*>(qd + BKP * QR + eo) = m;
       *reinterpret_cast<bf16x4*>(qd + 2 * BKP * QR + eo) = l;
