@@ -85,6 +85,73 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
   }
 }
 
+// Per-thread operand fetch shared by the fp32 and the split-bf16 kernel: thread (lrow, kc) gathers float4 number kc of
+// the K slice for A_LD rows of the im2col matrix (zero outside the image / past M) and B_LD rows of the filter.
+// K order: channel slice outermost, the KH*KW taps innermost.  The taps of one slice re-read (shifted) the same few KB
+// of input, which then come from L1/L2; tap-outermost order re-streamed the whole input tile per tap and the PMC pass
+// showed 5x the algorithmic HBM fetch on the 512-channel layers.
+template <int A_LD, int B_LD, int BK, int RPP>
+struct IgemmGather {
+  int lrow, kc, ntaps;
+  int a_pix[A_LD];             // b*H*W, or -1 when the row is past M
+  int a_ih0[A_LD], a_iw0[A_LD];
+  const float* b_ptr[B_LD];    // filter row of slot j (+ kc*4), or null past N
+  f32x4 a_reg[A_LD], b_reg[B_LD];
+
+  __device__ __forceinline__ void init(const ConvArgs& p, int tid, int m0, int n0) {
+    constexpr int KCH = BK / 4;
+    lrow = tid / KCH;
+    kc = tid % KCH;
+    ntaps = p.KH * p.KW;
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int m = m0 + lrow + RPP * i;
+      if (m < p.M) {
+        const int b = m / ohw;
+        const int rem = m - b * ohw;
+        const int oh = rem / p.OW;
+        const int ow = rem - oh * p.OW;
+        a_pix[i] = b * p.H * p.W;
+        a_ih0[i] = oh * p.stride_h - p.pad_h;
+        a_iw0[i] = ow * p.stride_w - p.pad_w;
+      } else {
+        a_pix[i] = -1;
+        a_ih0[i] = 0;
+        a_iw0[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int n = n0 + lrow + RPP * j;
+      b_ptr[j] = (n < p.N) ? (p.w + (size_t)n * p.K + kc * 4) : nullptr;
+    }
+  }
+
+  __device__ __forceinline__ void fetch(const ConvArgs& p, int kt) {
+    const int cs = kt / ntaps;
+    const int tap = kt - cs * ntaps;
+    const int c0 = cs * BK;
+    const int kh = tap / p.KW;
+    const int kw = tap - kh * p.KW;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+      const bool ok = (a_pix[i] >= 0) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_pix[i] + ih * p.W + iw) * p.ldx + c0 + kc * 4);
+      a_reg[i] = v;
+    }
+    const int koff = tap * p.Cin + c0;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ptr[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + koff);
+      b_reg[j] = v;
+    }
+  }
+};
+
 // Cin must be a multiple of 32 (checked by the entry point); the K-slice BK is 16 or 32
 
 template <int BM, int BN, int WGM, int WGN, int BK>
@@ -115,78 +182,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvAr
   const int tile_n = tile % p.n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- per-thread gather coordinates (fixed over the K loop) ----
-  const int lrow = tid / KCH;  // 0..RPP-1
-  const int kc = tid % KCH;    // which float4 of the K-slice
-  int a_pix[A_LD];            // b*H*W, or -1 when the row is past M
-  int a_ih0[A_LD], a_iw0[A_LD];
-  const int ohw = p.OH * p.OW;
-#pragma unroll
-  for (int i = 0; i < A_LD; ++i) {
-    const int m = m0 + lrow + RPP * i;
-    if (m < p.M) {
-      const int b = m / ohw;
-      const int rem = m - b * ohw;
-      const int oh = rem / p.OW;
-      const int ow = rem - oh * p.OW;
-      a_pix[i] = b * p.H * p.W;
-      a_ih0[i] = oh * p.stride_h - p.pad_h;
-      a_iw0[i] = ow * p.stride_w - p.pad_w;
-    } else {
-      a_pix[i] = -1;
-      a_ih0[i] = 0;
-      a_iw0[i] = 0;
-    }
-  }
-  const float* b_ptr[B_LD];
-#pragma unroll
-  for (int j = 0; j < B_LD; ++j) {
-    const int n = n0 + lrow + RPP * j;
-    b_ptr[j] = (n < p.N) ? (p.w + (size_t)n * p.K + kc * 4) : nullptr;
-  }
-
-  const int cin_steps = p.Cin / BK;
-  const int KT = p.KH * p.KW * cin_steps;
-
-  f32x4 a_reg[A_LD], b_reg[B_LD];
-  // K order: channel slice outermost, the KH*KW taps innermost.  The taps of one slice re-read (shifted) the same
-  // few KB of input, which then come from L1/L2; tap-outermost order re-streamed the whole input tile per tap and
-  // the PMC pass showed 5x the algorithmic HBM fetch on the 512-channel layers.
-  const int ntaps = p.KH * p.KW;
-  auto gather = [&](int kt) {
-    const int cs = kt / ntaps;
-    const int tap = kt - cs * ntaps;
-    const int c0 = cs * BK;
-    const int kh = tap / p.KW;
-    const int kw = tap - kh * p.KW;
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-      const bool ok = (a_pix[i] >= 0) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const float* src = p.x + (size_t)(a_pix[i] + ih * p.W + iw) * p.ldx + c0 + kc * 4;
-        v = *reinterpret_cast<const f32x4*>(src);
-      }
-      a_reg[i] = v;
-    }
-    const int koff = tap * p.Cin + c0;
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ptr[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + koff);
-      b_reg[j] = v;
-    }
-  };
+  IgemmGather<A_LD, B_LD, BK, RPP> g;
+  g.init(p, tid, m0, n0);
+  const int lrow = g.lrow, kc = g.kc;
+  const int KT = p.KH * p.KW * (p.Cin / BK);
+  auto gather = [&](int kt) { g.fetch(p, kt); };
   auto stage = [&](int buf) {
     float* a_dst = As + buf * BM * LDS_LD;
     float* b_dst = Bs + buf * BN * LDS_LD;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<f32x4*>(a_dst + (lrow + RPP * i) * LDS_LD + kc * 4) = a_reg[i];
+      *reinterpret_cast<f32x4*>(a_dst + (lrow + RPP * i) * LDS_LD + kc * 4) = g.a_reg[i];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
-      *reinterpret_cast<f32x4*>(b_dst + (lrow + RPP * j) * LDS_LD + kc * 4) = b_reg[j];
+      *reinterpret_cast<f32x4*>(b_dst + (lrow + RPP * j) * LDS_LD + kc * 4) = g.b_reg[j];
   };
 
   f32x16 acc[MI][NJ];
@@ -261,8 +270,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvAr
 // fp32-equivalent ceiling against 154 for v_mfma_f32_32x32x2_f32.  One K stage = 16 channels of one tap = one MFMA
 // k-step; LDS holds [plane][row][16 bf16] (32-byte rows, halves of rows 8..15 mod 16 swapped: conflict-free ds_read_b128).
 // ---------------------------------------------------------------------------------------------
+// (the 8-wave tiles must stay within 128 VGPRs: two workgroups, i.e. four waves per SIMD, share a CU)
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(WGM * WGN == 8 ? 4 : 1)))
+void conv_igemm_bf3_kernel(const ConvArgs p) {
   constexpr int BK = 16;
   constexpr int NT = WGM * WGN * 64;
   constexpr int ROWB = 16;                     // bf16 elements per LDS row: 32 bytes, unpadded; the two 16-byte halves of rows
@@ -285,64 +296,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const Co
   const int tile_m = tile / p.n_tiles, tile_n = tile % p.n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int lrow = tid / KCH, kc = tid % KCH;
-  int a_pix[A_LD], a_ih0[A_LD], a_iw0[A_LD];
-  const int ohw = p.OH * p.OW;
-#pragma unroll
-  for (int i = 0; i < A_LD; ++i) {
-    const int m = m0 + lrow + RPP * i;
-    if (m < p.M) {
-      const int b = m / ohw;
-      const int rem = m - b * ohw;
-      const int oh = rem / p.OW;
-      const int ow = rem - oh * p.OW;
-      a_pix[i] = b * p.H * p.W;
-      a_ih0[i] = oh * p.stride_h - p.pad_h;
-      a_iw0[i] = ow * p.stride_w - p.pad_w;
-    } else {
-      a_pix[i] = -1;
-      a_ih0[i] = 0;
-      a_iw0[i] = 0;
-    }
-  }
-  const float* b_ptr[B_LD];
-#pragma unroll
-  for (int j = 0; j < B_LD; ++j) {
-    const int n = n0 + lrow + RPP * j;
-    b_ptr[j] = (n < p.N) ? (p.w + (size_t)n * p.K + kc * 4) : nullptr;
-  }
-  const int ntaps = p.KH * p.KW;
-  const int KT = ntaps * (p.Cin / BK);
-
-  f32x4 a_reg[A_LD], b_reg[B_LD];
-  auto gather = [&](int kt) {
-    const int cs = kt / ntaps;
-    const int tap = kt - cs * ntaps;
-    const int c0 = cs * BK;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-      const bool ok = (a_pix[i] >= 0) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_pix[i] + ih * p.W + iw) * p.ldx + c0 + kc * 4);
-      a_reg[i] = v;
-    }
-    const int koff = tap * p.Cin + c0;
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ptr[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + koff);
-      b_reg[j] = v;
-    }
-  };
+  IgemmGather<A_LD, B_LD, BK, RPP> g;
+  g.init(p, tid, m0, n0);
+  const int lrow = g.lrow, kc = g.kc;
+  const int KT = p.KH * p.KW * (p.Cin / BK);
+  auto gather = [&](int kt) { g.fetch(p, kt); };
   auto stage = [&](int buf) {
     __bf16* a_dst = As + (size_t)buf * 3 * BM * ROWB;
     __bf16* b_dst = Bs + (size_t)buf * 3 * BN * ROWB;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       bf16x4 h, m, l;
-      qea_split3(a_reg[i], h, m, l);
+      qea_split3(g.a_reg[i], h, m, l);
       const int ro = lrow + RPP * i;
       const int o = ro * ROWB + (((kc >> 1) ^ ((ro >> 3) & 1)) << 3) + (kc & 1) * 4;
       *reinterpret_cast<bf16x4*>(a_dst + o) = h;
@@ -352,7 +317,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_bf3_kernel(const Co
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       bf16x4 h, m, l;
-      qea_split3(b_reg[j], h, m, l);
+      qea_split3(g.b_reg[j], h, m, l);
       const int ro = lrow + RPP * j;
       const int o = ro * ROWB + (((kc >> 1) ^ ((ro >> 3) & 1)) << 3) + (kc & 1) * 4;
       *reinterpret_cast<bf16x4*>(b_dst + o) = h;
