@@ -622,9 +622,9 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     else if (halo_eligible(d)) tile = 4;
     else if (d->N <= 32) tile = 3;
     else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep; the split-bf16 256x64 tile is slower here)
-    else if (bf3 && d->N % 256 == 0 && tiles22 >= 256) tile = 22;
-    else if (bf3 && tiles21 >= 256) tile = 21;
-    else if (bf3) tile = 20;
+    else if (bf3 && d->N % 256 == 0 && tiles22 >= 512) tile = 22;
+    else if (bf3 && tiles21 >= 512) tile = 21;
+    else if (bf3) tile = 25;  // small grids: 8 waves on a 128x128 tile (146-166 vs 110-150 TFLOP/s for the 4-wave tile 20)
     else if (d->N % 256 == 0 && tiles8 >= 1024) tile = 8;
     else if (tiles7 >= 512) tile = 7;
     else if (tiles128 >= 2048) tile = 5;
@@ -651,6 +651,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 21: rc = launch_bf3<256, 128, 4, 2>(a, s); break;
     case 22: rc = launch_bf3<128, 256, 2, 4>(a, s); break;
     case 23: rc = launch_bf3<256, 64, 4, 1>(a, s); break;
+    case 25: rc = launch_bf3<128, 128, 4, 2>(a, s); break;  // 8 waves on a 128x128 tile: small grids (about one workgroup per CU)
     default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
   }
   if (rc != QEA_OK) return rc;

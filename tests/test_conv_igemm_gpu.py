@@ -52,7 +52,7 @@ def test_conv3x3_shapes(H, W, Cin, Cout):
     _run(3, H, W, Cin, Cout, 3, 3, 1)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6, 7, 8, 9, 20, 21, 22, 23])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6, 7, 8, 9, 20, 21, 22, 23, 25])
 def test_conv3x3_all_tiles_ragged(tile):
     # M = 5*7*9 = 315 and N = 40 are not multiples of any tile edge
     _run(5, 7, 9, 64, 40, 3, 3, 1, relu=True, bias=True, tile=tile)
