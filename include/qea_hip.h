@@ -53,6 +53,14 @@ int qea_prof_read_launches(int klass, double* ms, double* flops, int64_t capacit
  * multiply-add): bench.py blends the fp32 and the bf16/6 matrix peaks with it. */
 int qea_prof_read_split_bf16(int klass, double* flops);
 
+/* Which matrix instruction the GEMM-class launches use: 0 = split-bf16 tiles where the dispatcher prefers them
+ * (default), 1 = every product on v_mfma_f32_32x32x2_f32.  The initial value comes from QEA_MFMA=f32 in the
+ * environment; tests and bench.py's native-fp32 leg switch it at run time.  Returns the previous mode, or
+ * QEA_ERR_INVALID for a mode other than 0/1 (mode -1 only queries). */
+#define QEA_MFMA_SPLIT_BF16 0
+#define QEA_MFMA_F32 1
+int qea_set_mfma_mode(int mode);
+
 /* ------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the matrix cores with fp32-class accuracy: v_mfma_f32_32x32x2_f32, or — by default
  * for N >= 64-128 output channels and K >= 256 (tiles 20-23) — the split-bf16 form: fp32 operands split on the fly into

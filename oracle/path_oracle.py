@@ -158,12 +158,16 @@ def topk_query(cers_dict, names, k):
 
 
 def padder(crop, h, w):
-    """utils.py:118-125 — centre a [C,ch,cw] crop on a white (1.0) h x w canvas."""
+    """utils.py:118-125 — centre a [C,ch,cw] crop on a white (1.0) h x w canvas.  ConstantPad2d with a NEGATIVE pad
+    crops: left = floor((w - cw) / 2) (Python floor division), so an oversize crop loses |left| columns on the left and
+    the rest on the right; out[y, x] = crop[y - top, x - left] wherever that index exists, else 1."""
     _, ch, cw = crop.shape
     left = (w - cw) // 2
     top = (h - ch) // 2
     out = np.ones((crop.shape[0], h, w), dtype=crop.dtype)
-    out[:, top:top + ch, left:left + cw] = crop
+    ys, xs = np.arange(h) - top, np.arange(w) - left
+    oky, okx = (ys >= 0) & (ys < ch), (xs >= 0) & (xs < cw)
+    out[:, np.ix_(oky, okx)[0], np.ix_(oky, okx)[1]] = crop[:, ys[oky]][:, :, xs[okx]]
     return out
 
 

@@ -4,6 +4,8 @@
 // All HBM- or latency-bound; bytes noted per entry point in include/qea_hip.h.
 #include "common.h"
 
+static __device__ __forceinline__ int qea_floordiv2(int d) { return d >= 0 ? d / 2 : -((-d + 1) / 2); }
+
 namespace {
 
 // ------------------------------------------------------------------ Adam
@@ -154,7 +156,9 @@ __global__ void crop_pad_gather_kernel(const float* __restrict__ img, int H, int
     const int n = (int)(i / ((long long)OW * OH));
     const int x0 = boxes[n * 4 + 0], y0 = boxes[n * 4 + 1], x1 = boxes[n * 4 + 2], y1 = boxes[n * 4 + 3];
     const int cw = x1 - x0, ch = y1 - y0;
-    const int left = (OW - cw) / 2, top = (OH - ch) / 2;
+    // Python floor division as in padder (utils.py:118-126): a crop larger than the target by an odd amount loses the
+    // EXTRA pixel on the left/top (negative padding), where C's truncation would take it from the right/bottom
+    const int left = qea_floordiv2(OW - cw), top = qea_floordiv2(OH - ch);
     const int sx = ox - left, sy = oy - top;
     float v = 1.f;
     if (sx >= 0 && sx < cw && sy >= 0 && sy < ch) v = img[(size_t)(y0 + sy) * W + x0 + sx];
@@ -171,7 +175,9 @@ __global__ void crop_pad_scatter_kernel(const float* __restrict__ dout, const in
     const int n = (int)(i / ((long long)OW * OH));
     const int x0 = boxes[n * 4 + 0], y0 = boxes[n * 4 + 1], x1 = boxes[n * 4 + 2], y1 = boxes[n * 4 + 3];
     const int cw = x1 - x0, ch = y1 - y0;
-    const int left = (OW - cw) / 2, top = (OH - ch) / 2;
+    // Python floor division as in padder (utils.py:118-126): a crop larger than the target by an odd amount loses the
+    // EXTRA pixel on the left/top (negative padding), where C's truncation would take it from the right/bottom
+    const int left = qea_floordiv2(OW - cw), top = qea_floordiv2(OH - ch);
     const int sx = ox - left, sy = oy - top;
     if (sx >= 0 && sx < cw && sy >= 0 && sy < ch) atomicAdd(dimg + (size_t)(y0 + sy) * W + x0 + sx, dout[i]);
   }

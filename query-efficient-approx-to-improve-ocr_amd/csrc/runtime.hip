@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -28,12 +29,22 @@ void qea_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-bool qea_split_bf16_enabled() {
-  static const int on = [] {
+namespace {
+std::atomic<int>& mfma_mode() {
+  static std::atomic<int> mode([] {
     const char* e = getenv("QEA_MFMA");
-    return (e && strcmp(e, "f32") == 0) ? 0 : 1;
-  }();
-  return on != 0;
+    return (e && strcmp(e, "f32") == 0) ? QEA_MFMA_F32 : QEA_MFMA_SPLIT_BF16;
+  }());
+  return mode;
+}
+}  // namespace
+
+bool qea_split_bf16_enabled() { return mfma_mode().load(std::memory_order_relaxed) == QEA_MFMA_SPLIT_BF16; }
+
+extern "C" int qea_set_mfma_mode(int mode) {
+  if (mode == -1) return mfma_mode().load();
+  QEA_REQUIRE(mode == QEA_MFMA_SPLIT_BF16 || mode == QEA_MFMA_F32, "qea_set_mfma_mode: bad mode %d", mode);
+  return mfma_mode().exchange(mode);
 }
 
 extern "C" const char* qea_last_error(void) { return g_err; }

@@ -66,6 +66,19 @@ def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride
     _lib.check(L.qea_conv_wgrad(C.byref(d), _stream()), "qea_conv_wgrad")
 
 
+def set_mfma_mode(mode):
+    """"split_bf16" (default dispatch) or "f32" (every product on the fp32 MFMA); returns the previous mode's name."""
+    names = ("split_bf16", "f32")
+    prev = _lib.lib().qea_set_mfma_mode(names.index(mode))
+    if prev < 0:
+        _lib.check(prev, "qea_set_mfma_mode")
+    return names[prev]
+
+
+def mfma_mode():
+    return ("split_bf16", "f32")[_lib.lib().qea_set_mfma_mode(-1)]
+
+
 _overlap = {"on": None}
 
 

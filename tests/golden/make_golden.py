@@ -444,8 +444,338 @@ def make_step():
     print("step", losses, lossB.item(), idx)
 
 
+# ============================================================================================
+# Round 2: KNIFE-EDGE-FREE fixtures.
+#
+# The fixtures above (He-normal weights, random running statistics, B = 2-4 at 32x128) cannot carry north_star's
+# "grads within 1e-4": the gradient of a ReLU / max-pool network is a DISCONTINUOUS function of its forward
+# activations, and at 32x128 every pass evaluates ~1 M decisions per image.  Measured here on the reference itself
+# (default-init distributions, uniform images, B = 4): in 11 of 12 (weight seed, image seed) pairs the reference's own
+# fp32 run differs from its fp64 run by 2.5e-3 ... 1.1e-2 on some gradient tensor (one flipped decision moves the weight
+# gradient below it by ~1/sqrt(#pixels)); the one clean pair moves by 6.5e-3 under a 1e-7 relative input perturbation;
+# and the smallest |pre-activation| of a layer is 5-100x SMALLER than that layer's fp32-vs-fp64 error in every candidate.
+# A decision-flip-free comparison between two independent fp32 implementations therefore only exists where the decision
+# count is small: the fixtures below use the same two networks at B = 2 on 32x32 and 32x64 images (T = 7 / 15), and a
+# candidate is accepted only if NINE fp32 evaluations of the reference (default, reversed batch order = another BatchNorm
+# summation order, one thread, and six draws of the input moved by <= 1 fp32 ulp) ALL agree with the
+# fp64 run to COND_MAX on EVERY gradient tensor of both phases.  The HIP path is then gated on them at a plain
+# ||g - g64|| / ||g64|| <= 1e-4 on full tensors (tests/test_conditioned_gpu.py).
+# ============================================================================================
+COND_MAX = 2.5e-5
+ZERO_GRAD = ("convo.conv5.bias", "convo.conv6.bias")   # exactly zero in Phase A (bias in front of a batch-statistics BatchNorm)
+
+
+def _bn_eval(net):
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    return net
+
+
+def load_default(module, shapes, seed):
+    st = mo.default_init_state(shapes, seed)
+    assert not (set(module.state_dict().keys()) ^ set(st.keys()))
+    module.load_state_dict(st)
+    return module
+
+
+def _ref_models(ws, dt):
+    prep = load_default(UNet(), mo.unet_state_shapes(), ws).to(dt)
+    crnn = load_default(CRNN(95, False), mo.crnn_state_shapes(), ws + 1).to(dt)
+    crnn.register_backward_hook(crnn.backward_hook)
+    return prep, crnn
+
+
+class RefRunner:
+    """The reference modules for one weight seed, re-armed (state reloaded) before every evaluation."""
+
+    def __init__(self, ws):
+        self.ws = ws
+        self.m, self.st = {}, {}
+        for dt in (torch.float32, torch.float64):
+            prep, crnn = _ref_models(ws, dt)
+            self.m[dt] = (prep, crnn)
+            self.st[dt] = ({k: v.clone() for k, v in prep.state_dict().items()}, {k: v.clone() for k, v in crnn.state_dict().items()})
+
+    def arm(self, dt):
+        prep, crnn = self.m[dt]
+        prep.load_state_dict(self.st[dt][0]); crnn.load_state_dict(self.st[dt][1])
+        prep.zero_grad(); crnn.zero_grad()
+        prep.train(); crnn.train()
+        return prep, crnn
+
+    def phase_b(self, dt, x, labels, variant="default"):
+        """train_nn_area.py:277-287: UNet(train) -> CRNN(train, BN eval) -> CTC + MSE -> backward."""
+        prep, crnn = self.arm(dt)
+        _bn_eval(crnn)
+        xi, perm = _variant_input(x.to(dt), variant)
+        lab = [labels[i] for i in perm]
+        img = prep(xi)
+        lp = crnn(img)
+        y, ysz = encode(lab)
+        ins = torch.tensor([lp.shape[0]] * x.shape[0], dtype=torch.int)
+        loss = torch.nn.CTCLoss()(lp, y, ins, ysz) + torch.nn.MSELoss()(img, torch.ones_like(img))
+        loss.backward()
+        inv = torch.argsort(torch.tensor(perm))
+        return dict(prep=prep, crnn=crnn, img=img.detach()[inv], lp=lp.detach()[:, inv], loss=loss.item())
+
+    def phase_a(self, dt, x, labels, variant="default"):
+        """train_nn_area.py:262-271: CRNN(train-mode BN) -> CTC -> backward; gradient wrt the input kept."""
+        _, crnn = self.arm(dt)
+        xi, perm = _variant_input(x.to(dt), variant)
+        xi = xi.clone().requires_grad_()
+        lab = [labels[i] for i in perm]
+        lp = crnn(xi)
+        y, ysz = encode(lab)
+        ins = torch.tensor([lp.shape[0]] * x.shape[0], dtype=torch.int)
+        loss = torch.nn.CTCLoss()(lp, y, ins, ysz)
+        loss.backward()
+        inv = torch.argsort(torch.tensor(perm))
+        return dict(crnn=crnn, dx=xi.grad.detach()[inv], lp=lp.detach()[:, inv], loss=loss.item())
+
+
+FP32_VARIANTS = ("default", "reversed", "one_thread", "ulp5", "ulp6", "ulp7", "ulp8", "ulp9", "ulp10")
+
+
+def _variant_input(x, variant):
+    """Independent fp32 evaluations of the same function: another summation order of the batch statistics (reversed
+    batch), another reduction partition (one thread), and six draws of the inputs moved by <= 1 fp32 ulp (every
+    downstream rounding then falls differently; this is the variant that rejects most candidates)."""
+    perm = list(range(x.shape[0]))
+    if variant == "reversed":
+        perm = perm[::-1]
+        x = x[perm].contiguous()
+    elif variant.startswith("ulp"):
+        g = torch.Generator().manual_seed(int(variant[3:]))
+        x = (x.double() * (1 + 5.96e-8 * (torch.rand(x.shape, generator=g, dtype=torch.float64) * 2 - 1))).to(x.dtype)
+    return x, perm
+
+
+def _grads(named):
+    return {n: p.grad.detach().double().clone() for n, p in named}
+
+
+def _worst_rel(ga, g64, skip=()):
+    return max(((ga[n] - g64[n]).norm() / g64[n].norm().clamp_min(1e-300)).item() for n in g64 if n not in skip)
+
+
+def _candidate_ok(R, x, labels, labels_a):
+    """-> (accepted, per-variant worst deviations).  Cheapest rejections first."""
+    figs = {}
+    b64 = R.phase_b(torch.float64, x, labels)
+    gB = {**{"prep." + n: g for n, g in _grads(b64["prep"].named_parameters()).items()},
+          **{"crnn." + n: g for n, g in _grads(b64["crnn"].named_parameters()).items()}}
+    a64 = R.phase_a(torch.float64, x, labels_a)
+    gA = {**_grads(a64["crnn"].named_parameters()), "dx": a64["dx"].double()}
+    for v in FP32_VARIANTS:
+        if v == "one_thread":
+            torch.set_num_threads(1)
+        try:
+            b = R.phase_b(torch.float32, x, labels, v)
+            g = {**{"prep." + n: q for n, q in _grads(b["prep"].named_parameters()).items()},
+                 **{"crnn." + n: q for n, q in _grads(b["crnn"].named_parameters()).items()}}
+            wb = _worst_rel(g, gB)
+            if wb > COND_MAX:
+                return False, {**figs, v: ("B", wb)}
+            a = R.phase_a(torch.float32, x, labels_a, v)
+            wa = _worst_rel({**_grads(a["crnn"].named_parameters()), "dx": a["dx"].double()}, gA, skip=ZERO_GRAD)
+            if wa > COND_MAX:
+                return False, {**figs, v: ("A", wa)}
+            figs[v] = max(wb, wa)
+        finally:
+            torch.set_num_threads(8)
+    return True, figs
+
+
+def full64(named_params64, prefix, out):
+    """Per tensor of the fp64 reference run: |s64 (values at sample_index), |l264, |sum64, |abs64."""
+    for name, p in named_params64:
+        g64 = p.grad.detach().double().flatten()
+        out[f"{prefix}{name}|s64"] = g64[sample_index(g64.numel())].numpy().copy()
+        out[f"{prefix}{name}|l264"] = g64.norm().item()
+        out[f"{prefix}{name}|sum64"] = g64.sum().item()
+        out[f"{prefix}{name}|abs64"] = g64.abs().sum().item()
+
+
+def make_conditioned():
+    """tests/golden/cond_b2w32.npz, cond_b4w64.npz, cond_b4w128.npz: for each shape the FIRST image seed (fixed weight seed, fixed seed
+    order) that passes _candidate_ok; the rejected seeds and their figures are stored with it."""
+    for B, W, ws, xs0 in ((2, 32, 50, 1000), (4, 64, 54, 4000), (4, 128, 56, 3000)):
+        T = W // 4 - 1
+        R = RefRunner(ws)
+        log = []
+        for xs in range(xs0, xs0 + 600):
+            x = torch.rand(B, 1, 32, W, generator=torch.Generator().manual_seed(xs))
+            labels = synth_labels(B, xs, 1, max(1, T // 2))
+            labels_a = synth_labels(B, xs + 100, 1, max(1, T // 2))
+            ok, figs = _candidate_ok(R, x, labels, labels_a)
+            log.append(f"{xs}:{'ok' if ok else 'rejected'}:{figs}")
+            if ok:
+                break
+        else:
+            raise SystemExit(f"B={B} W={W}: no knife-edge-free candidate in 600 seeds")
+        print(f"cond B={B} W={W}: accepted image seed {xs} after {len(log) - 1} rejections; fp32 variants vs fp64: {figs}")
+        out = {"x": x.numpy(), "labels": np.array(labels), "labels_a": np.array(labels_a), "ws": ws, "xs": xs, "W": W, "B": B,
+               "search_log": np.array(log), "variant_worst": np.array([figs[v] for v in FP32_VARIANTS])}
+        b64 = R.phase_b(torch.float64, x, labels)
+        full64(b64["prep"].named_parameters(), "B|g|prep|", out)
+        full64(b64["crnn"].named_parameters(), "B|g|crnn|", out)
+        out.update({"B|loss64": b64["loss"], "B|img64": b64["img"].numpy(), "B|lp64": b64["lp"].numpy(),
+                    "B|loss32": R.phase_b(torch.float32, x, labels)["loss"]})
+        for k, v in b64["prep"].state_dict().items():
+            if mo.is_buffer(k) and v.is_floating_point():
+                out[f"B|buf|{k}"] = v.numpy().copy()
+        a64 = R.phase_a(torch.float64, x, labels_a)
+        full64(a64["crnn"].named_parameters(), "A|g|", out)
+        out.update({"A|loss64": a64["loss"], "A|lp64": a64["lp"].numpy(), "A|dx64": a64["dx"].numpy(),
+                    "A|loss32": R.phase_a(torch.float32, x, labels_a)["loss"]})
+        for k, v in a64["crnn"].state_dict().items():
+            if mo.is_buffer(k) and v.is_floating_point():
+                out[f"A|buf|{k}"] = v.numpy().copy()
+        np.savez_compressed(os.path.join(HERE, f"cond_b{B}w{W}.npz"), **out)
+
+
+def make_crop_oversize():
+    """tests/golden/crop_oversize.npz — get_text_stack / padder (utils.py:118-141) on boxes LARGER than 32x128 by odd and
+    even amounts: ConstantPad2d with negative pads crops, and Python floor division decides which side loses the extra pixel."""
+    _, padder, get_text_stack = ref_defs("utils.py", ["pred_to_string", "padder", "get_text_stack"])
+    g = torch.Generator().manual_seed(23)
+    page = torch.rand(1, 80, 300, generator=g)
+    boxes = [dict(label="a", x_min=5, y_min=3, x_max=136, y_max=38),      # 131 x 35: odd oversize both ways
+             dict(label="b", x_min=100, y_min=40, x_max=230, y_max=74),   # 130 x 34: even oversize
+             dict(label="c", x_min=0, y_min=0, x_max=129, y_max=20),      # 129 wide (odd), 20 high (padded)
+             dict(label="d", x_min=200, y_min=10, x_max=260, y_max=43)]   # 60 wide (padded), 33 high (odd oversize)
+    stack, _ = get_text_stack(page, boxes, (32, 128))
+    np.savez_compressed(os.path.join(HERE, "crop_oversize.npz"), page=page.numpy(), stack=stack.numpy(),
+                        boxes=np.array([[b["x_min"], b["y_min"], b["x_max"], b["y_max"]] for b in boxes]))
+    print("crop_oversize", stack.shape)
+
+
+def make_area_step():
+    """tests/golden/area_step_b8.npz — ONE minibatch of train_nn_area.TrainNNPrep.train (train_nn_area.py:212-304) on the
+    reference modules from default-distribution weights, chained A -> B exactly as the trainer does it: TopKCER (prop 0.5),
+    2 jitter replicas with recorded noise, the stub label source (GT reversed), CTC, backward of the last replica,
+    Adam(CRNN); UNet(train) -> CRNN(BN eval) -> CTC + MSE -> Adam(UNet); decode + CER update.  Driven on the HIP side
+    through TrainNNPrep itself (tests/test_trainers_gpu.py::test_area_trainer_one_minibatch_vs_reference)."""
+    out = {}
+    B, inner, prop, std, ws = 8, 2, 0.5, 5, 20
+    x = torch.rand(B, 1, 32, 128, generator=torch.Generator().manual_seed(31))
+    labels = synth_labels(B, 33, 2, 8)
+    names = [f"img{i}.png" for i in range(B)]
+    cers = {n: c for n, c in zip(names, [0.25, 0.8, 0.0, 0.5, 0.9, 0.1, 0.3, 0.7])}
+    prep, crnn = _ref_models(ws, torch.float32)
+    opt_c = torch.optim.Adam(crnn.parameters(), lr=1e-4, weight_decay=0)
+    opt_p = torch.optim.Adam(prep.parameters(), lr=5e-5, weight_decay=0)
+    pre = {("prep|" + k): v.clone() for k, v in prep.state_dict().items()}
+    pre.update({("crnn|" + k): v.clone() for k, v in crnn.state_dict().items()})
+    ctc = torch.nn.CTCLoss()
+    sampler = selection_utils.datasampler_factory("topKCER")(dict(cers))
+    (pred_to_string,) = ref_defs("utils.py", ["pred_to_string"])
+    # ---- Phase A (train_nn_area.py:214-275)
+    crnn.train(); prep.eval(); prep.zero_grad(); crnn.zero_grad()
+    preds_all = prep(x)
+    k = max(1, math.ceil(B * (1 - prop)))
+    preds, labels_sel, idx = sampler.query(preds_all, labels, k, names)
+    preds = preds.detach()
+    out["A|idx"] = idx.numpy()
+    g = torch.Generator().manual_seed(35)
+    losses = []
+    for i in range(inner):
+        noise = torch.randn(preds.shape, generator=g) * (std / 100.0)
+        noisy = (preds - noise).clamp(0, 1)
+        out[f"A|noise{i}"] = noise.numpy()
+        ocr_labels = [l[::-1] for l in labels_sel]
+        lp = crnn(noisy)
+        y, ysz = encode(ocr_labels)
+        loss = ctc(lp, y, torch.tensor([lp.shape[0]] * len(ocr_labels), dtype=torch.int), ysz)
+        losses.append(loss.item())
+    loss.backward()
+    opt_c.step()
+    out["A|losses"] = np.array(losses)
+    # ---- Phase B (:277-287)
+    prep.train(); crnn.train(); _bn_eval(crnn)
+    prep.zero_grad(); crnn.zero_grad()
+    img = prep(x)
+    lp = crnn(img)
+    y, ysz = encode(labels)
+    lossB = ctc(lp, y, torch.tensor([lp.shape[0]] * B, dtype=torch.int), ysz) + torch.nn.MSELoss()(img, torch.ones_like(img)) * 1.0
+    lossB.backward()
+    opt_p.step()
+    out["B|loss"] = lossB.item()
+    # ---- CER update (:290-304)
+    i2c = {i: c for i, c in enumerate(properties.char_set)}
+    out["B|decoded"] = np.array(pred_to_string(lp.detach(), labels, i2c))
+    # post-step state: update (post - pre) of every parameter at sample_index + its l2 norm; buffers in full
+    for tag, net in (("prep|", prep), ("crnn|", crnn)):
+        for kname, v in net.state_dict().items():
+            if mo.is_buffer(kname):
+                if v.is_floating_point():
+                    out["post|" + tag + kname] = v.numpy().copy()
+                continue
+            d = (v.detach().double() - pre[tag + kname].double()).flatten()
+            out["upd|" + tag + kname + "|s"] = d[sample_index(d.numel())].numpy().copy()
+            out["upd|" + tag + kname + "|l2"] = d.norm().item()
+    out.update({"x": x.numpy(), "labels": np.array(labels), "names": np.array(names), "cers": np.array([cers[n] for n in names]),
+                "ws": ws, "inner": inner, "prop": prop, "std": std})
+    np.savez_compressed(os.path.join(HERE, "area_step_b8.npz"), **out)
+    print("area_step", losses, lossB.item(), idx.tolist(), out["B|decoded"])
+
+
+def make_tracking():
+    """tests/golden/tracking_b6.npz — the label-history branch (train_nn_patch.py:280-287) run with the REFERENCE's own
+    tracking_utils.py (imported unchanged) and DecayingWeightGenerator (label_tracking/tracking_methods.py:105-115,
+    compiled from the reference file: the module needs the absent python-Levenshtein): a 3-epoch OCR-label history with
+    ragged depth per strip, window 3, decay 0.7 -> generate_ctc_target_batches -> weighted_ctc_loss on the reference CRNN
+    (train-mode BN), loss + every CRNN gradient in fp32 and fp64."""
+    import abc
+    import types
+    import tracking_utils as rtu                                 # reference, root module
+    src = open(os.path.join(REF, "label_tracking", "tracking_methods.py")).read()
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("LossWeightGenerator", "DecayingWeightGenerator")]
+    ns = {"torch": torch, "ABCMeta": abc.ABCMeta, "abstractmethod": abc.abstractmethod}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "tracking_methods.py", "exec"), ns)
+    out = {}
+    B, ws, window, decay = 6, 40, 3, 0.7
+    x = torch.rand(B, 1, 32, 128, generator=torch.Generator().manual_seed(51))
+    names = [f"s{i}" for i in range(B)]
+    hist = [synth_labels(B, 60 + e, 1, 9) for e in range(3)]     # epoch 0, 1, 2 OCR labels
+    depth = [3, 1, 2, 3, 0, 2]                                   # how many past epochs each strip was queried in (0: new now)
+    c2i = {c: i for i, c in enumerate(properties.char_set)}
+    runs = {}
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        _, crnn = _ref_models(ws, dt)
+        crnn.train()
+        self = types.SimpleNamespace(device=torch.device("cpu"), crnn_model=crnn, char_to_index=c2i, window_size=window,
+                                     weightgen_method="decaying", primary_loss_fn=torch.nn.CTCLoss(),
+                                     primary_loss_fn_sample_wise=torch.nn.CTCLoss(reduction="none"),
+                                     tracked_labels={n: [hist[e][i] for e in range(3)][:depth[i]] for i, n in enumerate(names)})
+        wg = ns["DecayingWeightGenerator"](types.SimpleNamespace(decay_factor=decay, window_size=window), self.device)
+        current = synth_labels(B, 70, 1, 9)                      # this iteration's OCR labels
+        loss_weights = wg.gen_weights(self.tracked_labels, names)
+        rtu.add_labels_to_history(self, names, current)
+        batches = rtu.generate_ctc_target_batches(self, names)
+        scores, pred_size = rtu.call_crnn(self, x.to(dt))
+        loss = rtu.weighted_ctc_loss(self, scores, pred_size, batches, loss_weights)
+        loss.backward()
+        runs[tag] = (crnn, loss.item(), scores.detach(), batches, loss_weights, self.tracked_labels)
+    crnn32, l32, _, batches, lw, tracked = runs["32"]
+    crnn64, l64, sc64, _, _, _ = runs["64"]
+    full64(crnn64.named_parameters(), "g|", out)
+    out["dev32"] = _worst_rel(_grads(crnn32.named_parameters()), _grads(crnn64.named_parameters()), skip=ZERO_GRAD)
+    out.update({"x": x.numpy(), "loss32": l32, "loss64": l64, "lp64": sc64.numpy(), "weights": lw.numpy(), "window": window, "decay": decay,
+                "ws": ws, "names": np.array(names), "current": np.array(current),
+                "history_json": np.array(json.dumps({n: [hist[e][i] for e in range(3)][:depth[i]] for i, n in enumerate(names)})),
+                "tracked_after_json": np.array(json.dumps(tracked)),
+                "n_batches": len(batches)})
+    for i, (t, ts, idx) in enumerate(batches):
+        out[f"batch{i}|target"], out[f"batch{i}|size"], out[f"batch{i}|idx"] = t.numpy(), ts.numpy(), np.array(idx)
+    np.savez_compressed(os.path.join(HERE, "tracking_b6.npz"), **out)
+    print("tracking", l32, l64, [len(b[2]) for b in batches], lw.tolist())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["unet", "crnn", "ctc", "topk", "helpers", "step"]
+    which = sys.argv[1:] or ["unet", "crnn", "ctc", "topk", "helpers", "step", "conditioned", "area_step", "tracking", "crop_oversize"]
     for w in which:
         globals()["make_" + w]()

@@ -140,3 +140,58 @@ def check_grad_vs64(fix, prefix, named_grads, rtol=1e-4, k=3.0, atol=2e-7, repor
         if abs(g.norm().item() - l264) > (max(rtol, k * dev) if l264 > atol * g.numel() ** 0.5 else 1.0) * l264 + atol * g.numel() ** 0.5:
             bad.append((name, "l2", g.norm().item(), l264, dev))
     assert not bad, bad[:8]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round-2 knife-edge-free fixtures (tests/golden/cond_b*.npz): the oracle evaluated in fp64 on the fixture's inputs
+def _state64(shapes, seed):
+    from oracle import model_oracle as mo
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in mo.default_init_state(shapes, seed).items()}
+
+
+def oracle_cond_case(fx):
+    """-> (Phase-B result, Phase-A result) of the CPU oracle in fp64: losses, activations, FULL gradient tensors."""
+    import torch.nn.functional as F
+    from oracle import model_oracle as mo
+    ws = int(fx["ws"])
+    x = torch.from_numpy(fx["x"]).double()
+    labels, labels_a = [str(s) for s in fx["labels"]], [str(s) for s in fx["labels_a"]]
+    Pu, Bu = mo.split_state(_state64(mo.unet_state_shapes(), ws))
+    Pc, Bc = mo.split_state(_state64(mo.crnn_state_shapes(), ws + 1))
+    img = mo.unet_forward(Pu, Bu, x, training=True)
+    lp = mo.crnn_forward(Pc, Bc, img, bn_training=False)
+    y, ysz = encode(labels)
+    ins = torch.full((x.shape[0],), lp.shape[0], dtype=torch.int)
+    loss = F.ctc_loss(lp, y, ins, ysz) + F.mse_loss(img, torch.ones_like(img))
+    loss.backward()
+    rB = dict(loss=loss.item(), img=img.detach(), lp=lp.detach(), g_prep={k: p.grad for k, p in Pu.items()},
+              g_crnn={k: p.grad for k, p in Pc.items()}, buf_prep=Bu)
+    Pc2, Bc2 = mo.split_state(_state64(mo.crnn_state_shapes(), ws + 1))
+    xa = x.clone().requires_grad_()
+    lpa = mo.crnn_forward(Pc2, Bc2, xa, bn_training=True)
+    ya, ysa = encode(labels_a)
+    la = F.ctc_loss(lpa, ya, ins, ysa)
+    la.backward()
+    rA = dict(loss=la.item(), lp=lpa.detach(), dx=xa.grad, g_crnn={k: p.grad for k, p in Pc2.items()}, buf_crnn=Bc2)
+    return rB, rA
+
+
+def oracle_tracking_case(fx, batches, weights):
+    """weighted_ctc_loss (tracking_utils.py:59-75, decaying weights) on the oracle CRNN (train-mode BN), fp64."""
+    import torch.nn.functional as F
+    from oracle import model_oracle as mo
+    Pc, Bc = mo.split_state(_state64(mo.crnn_state_shapes(), int(fx["ws"]) + 1))
+    x = torch.from_numpy(fx["x"]).double()
+    lp = mo.crnn_forward(Pc, Bc, x, bn_training=True)
+    total = 0
+    for i, (t, ts, idx) in enumerate(batches):
+        ins = torch.full((len(idx),), lp.shape[0], dtype=torch.int)
+        total = total + float(weights[i]) * F.ctc_loss(lp[:, list(idx), :], t, ins, ts)
+    total.backward()
+    return dict(loss=total.item(), lp=lp.detach(), g_crnn={k: p.grad for k, p in Pc.items()})
+
+
+def full_rel_err(got, ref):
+    """plain || got - ref || / || ref || over the FULL tensor (no discard, no conditioning term)."""
+    got, ref = got.detach().double().flatten().cpu(), ref.detach().double().flatten().cpu()
+    return (got - ref).norm().item() / max(ref.norm().item(), 1e-300)

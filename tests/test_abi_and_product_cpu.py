@@ -69,3 +69,19 @@ def test_state_dict_layout_matches_reference_keys():
     assert set(c.keys()) == set(mo.crnn_state_shapes().keys())
     assert all(tuple(v.shape) == tuple(mo.crnn_state_shapes()[k]) for k, v in c.items())
     assert any(k.startswith("convo.module.") for k in CRNN(95).state_dict())      # multi_gpu=True naming of the reference
+
+
+def test_crnn_pickled_with_a_live_legacy_hook_loads_clean(tmp_path):
+    """the reference pickles the whole CRNN AFTER register_backward_hook, so its checkpoints restore a live
+    legacy hook; on load it must be replaced by the in-kernel scrub flag (the GPU forward/backward of such a module is
+    covered by tests/test_trainers_gpu.py::test_reference_style_crnn_pickle_trains)."""
+    import torch
+    from models.model_crnn import CRNN
+    net = CRNN(95, False)
+    torch.nn.Module.register_backward_hook(net, net.backward_hook)        # what the reference's class does (model_crnn.py:30-32)
+    assert len(net._backward_hooks) == 1
+    path = tmp_path / "CRNN_model_3"
+    torch.save(net, path)
+    back = torch.load(path, weights_only=False)
+    assert len(back._backward_hooks) == 0 and back.__dict__.get("_qea_nan_scrub") is True
+    back.backward_hook(back, (None, torch.tensor([float("nan"), 1.0])), None)   # None grads are skipped

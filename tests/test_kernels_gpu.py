@@ -445,16 +445,20 @@ def test_topk_bit_exact(golden_dir):
             assert got == c["idx"], c["note"]
 
 
-def test_crop_pad_gather_scatter():
+@pytest.mark.parametrize("fixture,pk,bk,sk", [("helpers.npz", "crop|page", "crop|boxes", "crop|stack"),
+                                               ("crop_oversize.npz", "page", "boxes", "stack")])
+def test_crop_pad_gather_scatter(fixture, pk, bk, sk):
+    """crop_oversize.npz: boxes larger than 32x128 by odd / even amounts (negative ConstantPad2d padding crops; Python
+    floor division decides which side loses the extra pixel — utils.py:118-126)."""
     from qea import ops
-    fx = H.golden("helpers.npz")
-    page = torch.from_numpy(fx["crop|page"])[0]
+    fx = H.golden(fixture)
+    page = torch.from_numpy(fx[pk])[0]
     Hh, Ww = page.shape
-    boxes = torch.from_numpy(fx["crop|boxes"].astype(np.int32))
+    boxes = torch.from_numpy(fx[bk].astype(np.int32))
     N = boxes.shape[0]
     out = torch.empty(N, 32, 128, device="cuda")
     ops.crop_pad_gather(page.cuda(), Hh, Ww, boxes.cuda(), N, 32, 128, out)
-    assert np.array_equal(out.cpu().numpy().reshape(fx["crop|stack"].shape), fx["crop|stack"])
+    assert np.array_equal(out.cpu().numpy().reshape(fx[sk].shape), fx[sk])
     g = torch.Generator().manual_seed(1)
     dout = torch.randn(N, 32, 128, generator=g)
     pr = page.clone().requires_grad_()
