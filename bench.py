@@ -1,19 +1,26 @@
-"""Headline benchmark: patch-images/sec through one Phase-B pass of the preprocessor-training
-inner loop (BASELINE.json metric) on N MI355X GPUs of one node.
+"""Headline benchmark: patch-images/sec through the preprocessor-training inner loop (BASELINE.json metric) on N MI355X
+GPUs of one node.  Default workload = BASELINE configs[2]: per-GPU minibatch of 2048 synthetic 32x128 grey patches, the
+FULL minibatch step of train_nn_area.py:212-287:
 
-  step = UNet(train BN) -> CRNN(train, BN eval) -> CTC(mean) + MSE(img, 1) -> backward
-         (UNet dgrad+wgrad, CRNN dgrad+wgrad: reference-faithful, 9.846 GFLOP/img) -> [RCCL
-         all-reduce of the flat UNet gradient when N > 1] -> fused Adam(UNet)
-  (reference: train_nn_area.py:277-287 / train_nn_patch.py:312-345)
+  Phase A: UNet(eval, no grad) -> TopKCER pick (minibatch_subset_prop 0.95: k = 5 % of the minibatch; whole-minibatch ranking
+           over the ranks when N > 1) -> inner_limit = 4 jitter replicas (one Philox launch, replicas fused in the batch dim)
+           -> CRNN(train-mode BN per replica group) -> CTC -> backward of the last replica -> [RCCL all-reduce of the flat
+           CRNN gradient] -> fused Adam(CRNN)
+  Phase B: UNet(train BN) -> CRNN(train, BN eval) -> CTC(mean) + MSE(img, 1) -> backward (UNet dgrad+wgrad, CRNN dgrad+wgrad:
+           reference-faithful, 9.846 GFLOP/img) -> [RCCL all-reduce of the flat UNet gradient] -> fused Adam(UNet)
 
-Inputs are synthetic POS-style 32x128 grey patches already resident in HBM, random-init weights,
-fp32 throughout.  One JSON line on rank 0 (contract in the task statement), plus
-  "roofline":     the implicit-GEMM MFMA conv kernel (dominant), algorithmic flops / HIP-event time
-                  measured over the timed region on the launch stream
-  "cpu_baseline": the CPU oracle (oracle/, a torch-CPU restatement pinned to the reference) timed on
-                  the host cores on a bounded sample — N=1 only.
+`value` = minibatch images / time of (Phase A + Phase B), whole job.  Secondary objects on the same line: `phase_b`
+(Phase-B-only rate at the same batch: the per-image unit of SURVEY.md §8d) and `configs1_b512` (BASELINE configs[1]: B = 512,
+Phase B).  `--phase-b-only` makes the Phase-B rate the `value` instead.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--full-step]
+Inputs are resident in HBM, random-init weights, fp32 storage.  One JSON line on rank 0 (contract in the task statement), plus
+  "roofline":     the implicit-GEMM MFMA conv class (dominant): algorithmic flops / HIP-event time over the same K steps
+                  re-run single-stream; and the SAME class with every product forced onto the fp32 MFMA instruction
+                  (`native_fp32`), against the 157.3 TFLOP/s fp32 matrix peak
+  "cpu_baseline": the CPU oracle (oracle/, a torch-CPU restatement pinned to the reference) timed on the host cores on a
+                  bounded sample at B = 32 and B = 128 — N = 1 only.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--phase-b-only]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -49,17 +56,49 @@ def synth_batch(B, seed, device):
     return x.to(device), y, lens.to(torch.int32)
 
 
-def cpu_baseline(batch=128, steps=8):
+def host_cpu():
+    """What the CPU baseline runs on: model name, logical CPUs, physical cores (unique (package, core) pairs of
+    /proc/cpuinfo), CPUs this process may run on."""
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        info["affinity_cpus"] = os.cpu_count()
+    try:
+        cores, model, phys, core = set(), None, None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        info["model"] = model
+        info["physical_cores"] = len(cores) or None
+    except OSError:
+        pass
+    return info
+
+
+def cpu_threads(host):
+    """threads for the CPU leg: the physical cores this process may use; a 1-GPU job on the GPU box has a 16-CPU share
+    whatever os.cpu_count() says, and OpenMP oversubscribed far beyond the share crawls (QEA_CPU_THREADS overrides)."""
+    if os.environ.get("QEA_CPU_THREADS"):
+        return max(1, int(os.environ["QEA_CPU_THREADS"]))
+    n = host.get("affinity_cpus") or 1
+    if host.get("physical_cores"):
+        n = min(n, host["physical_cores"])
+    return max(1, min(n, 16))
+
+
+def cpu_baseline_one(batch, steps, cores):
     """Phase-B step of the CPU oracle on the host cores (bounded sample)."""
     import torch.nn.functional as F
     from oracle import model_oracle as mo
-    # the GPU box gives a 1-GPU job a 16-core CPU share whatever os.cpu_count() says; oversubscribing
-    # OpenMP far beyond the share makes the CPU leg crawl
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, int(os.environ.get("QEA_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     x, y, lens = synth_batch(batch, 7, "cpu")
     Pu, Bu = mo.split_state(mo.seeded_state(mo.unet_state_shapes(), 1))
@@ -83,8 +122,32 @@ def cpu_baseline(batch=128, steps=8):
         step()
         print(f"[bench] cpu_baseline step {i + 1}/{steps} {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "patch-images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} Phase-B steps of B={batch} (+1 warm-up), CPU oracle, torch {torch.__version__} CPU fp32"}
+    return {"value": batch * steps / dt, "unit": "patch-images/s", "ms_per_step": dt / steps * 1e3, "batch": batch, "steps": steps}
+
+
+def cpu_baseline():
+    """B = 32 and B = 128, the node's core count stated.  ~25 s of CPU work in all."""
+    host = host_cpu()
+    cores = cpu_threads(host)
+    b128 = cpu_baseline_one(128, 6, cores)
+    b32 = cpu_baseline_one(32, 8, cores)
+    return {"value": b128["value"], "unit": "patch-images/s", "cores": cores, "kind": "port",
+            "sample": f"Phase-B steps (UNet train-BN -> CRNN -> CTC+MSE -> backward -> Adam) of the CPU oracle, torch {torch.__version__} CPU fp32: "
+                      f"6 steps of B=128 (value) and 8 steps of B=32, 1 warm-up each",
+            "b128": b128, "b32": b32, "host": host}
+
+
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources: stamps PMC profiles so that a stale one is refused."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "qea_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -92,17 +155,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="patches per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=2048, help="patches per GPU (weak scaling); BASELINE configs[2] = 2048, configs[1] = 512")
+    ap.add_argument("--phase-b-only", action="store_true", help="`value` = Phase-B-only rate (no Phase A in the timed region)")
+    ap.add_argument("--full-step", action="store_true", help="(default; kept for compatibility) `value` = Phase A + Phase B")
+    ap.add_argument("--inner-limit", type=int, default=4)
     ap.add_argument("--skip-crnn-wgrad", action="store_true",
                     help="skip the CRNN weight gradients the reference computes but discards when --update_CRNN is off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (B = 512) and native-fp32 legs")
     ap.add_argument("--graph", action="store_true",
-                    help="record the step into a hipGraph and time replays (single GPU; pays off at small --batch, where the step "
-                         "is bound by host launch time; at the default batch the step is GPU-bound)")
-    ap.add_argument("--full-step", action="store_true",
-                    help="also time Phase A + Phase B (TopKCER prop 0.95, inner_limit 4 jitter replicas, CRNN BN-train fwd/bwd, "
-                         "Adam(CRNN)) and report it as `full_step` (the headline `value` stays the Phase-B metric)")
+                    help="record the Phase-B step into a hipGraph and time replays (single GPU, implies --phase-b-only)")
     args = ap.parse_args()
+    if args.graph:
+        args.phase_b_only = True
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # convenience: `python bench.py --gpus N` starts the N ranks itself (as a child, before this process touches the GPU)
@@ -131,10 +196,13 @@ def main():
 
     from models.model_crnn import CRNN
     from models.model_unet import UNet
+    from qea import dist as qdist
     from qea import ops
     from qea.loss import CTCLoss
     from qea.optim import FusedAdam
     from qea.params import ensure_flat
+    from selection_utils import datasampler_factory
+    from transform_helper import AddGaussianNoice
 
     torch.manual_seed(42)
     prep = UNet().to(dev)
@@ -145,20 +213,35 @@ def main():
     if args.graph and use_dist:
         raise SystemExit("bench.py: --graph is a single-GPU option")
     opt_p = FusedAdam(prep.parameters(), lr=5e-5, weight_decay=0, capturable=args.graph)
+    opt_c = FusedAdam(crnn.parameters(), lr=1e-4, weight_decay=0)
     ctc = CTCLoss()
     mse = torch.nn.MSELoss()
-    B = args.batch
-    x, y, lens = synth_batch(B, 1000 + rank, dev)
-    ins = torch.full((B,), 31, dtype=torch.int32)
-    ones = torch.ones(B, 1, 32, 128, device=dev)
-    fs = ensure_flat(prep)
-    if args.graph:                                   # capturable form: device-resident targets, nothing read on the host
-        ctc.max_target_length = int(lens.max())
-        y_s, ins_s, lens_s = y.to(dev), ins.to(dev), lens.to(dev)
-    else:
-        y_s, ins_s, lens_s = y, ins, lens
+    fs, fc = ensure_flat(prep), ensure_flat(crnn)
+    R = args.inner_limit
 
-    def step():
+    class Work:
+        """one per-GPU minibatch of B patches with its labels, CER table and Phase-A label set"""
+
+        def __init__(self, B):
+            self.B = B
+            self.x, self.y, self.lens = synth_batch(B, 1000 + rank, dev)
+            self.ins = torch.full((B,), 31, dtype=torch.int32)
+            self.ones = torch.ones(B, 1, 32, 128, device=dev)
+            self.names = [f"r{rank}s{i}" for i in range(B)]
+            gen = torch.Generator().manual_seed(7 + rank)
+            self.sampler = datasampler_factory("topKCER")({n: float(c) for n, c in zip(self.names, torch.rand(B, generator=gen))})
+            self.k_global = max(1, -(-B * world * 5 // 100))         # ceil(0.05 * global minibatch): minibatch_subset_prop 0.95
+            self.off = torch.zeros(B + 1, dtype=torch.int64)
+            self.off[1:] = torch.cumsum(self.lens.to(torch.int64), 0)
+            if args.graph:                                           # capturable form: device-resident targets
+                ctc.max_target_length = int(self.lens.max())
+                self.y_s, self.ins_s, self.lens_s = self.y.to(dev), self.ins.to(dev), self.lens.to(dev)
+            else:
+                self.y_s, self.ins_s, self.lens_s = self.y, self.ins, self.lens
+
+    noiser = AddGaussianNoice(std=5, is_stochastic=True)
+
+    def phase_b(w):
         prep.train()
         crnn.train()
         for m in crnn.modules():
@@ -166,9 +249,9 @@ def main():
                 m.eval()
         prep.zero_grad()
         crnn.zero_grad()
-        img = prep(x)
+        img = prep(w.x)
         lp = crnn(img)
-        loss = ctc(lp, y_s, ins_s, lens_s) + mse(img, ones)
+        loss = ctc(lp, w.y_s, w.ins_s, w.lens_s) + mse(img, w.ones)
         loss.backward()
         if use_dist:
             dist.all_reduce(fs.grad)                 # one RCCL all-reduce of the flat 31 MB UNet gradient
@@ -177,34 +260,31 @@ def main():
         opt_p.step()
         return loss
 
-    # ---- Phase A (BASELINE configs[2..3]): the black-box OCR itself is outside the path; its labels are fixed here
-    from selection_utils import datasampler_factory
-    from transform_helper import AddGaussianNoice
-    names = [f"s{i}" for i in range(B)]
-    gen = torch.Generator().manual_seed(7)
-    sampler = datasampler_factory("topKCER")({n: float(c) for n, c in zip(names, torch.rand(B, generator=gen))})
-    noiser = AddGaussianNoice(std=5, is_stochastic=True)
-    opt_c = FusedAdam(crnn.parameters(), lr=1e-4, weight_decay=0)
-    kA = max(1, -(-B * 5 // 100))
-    yA, lensA = y[: int(lens[:kA].sum())], lens[:kA]
-    insA = torch.full((kA,), 31, dtype=torch.int32)
-    fc = ensure_flat(crnn)
-
-    def phase_a(inner_limit=4):
+    def phase_a(w):
+        """train_nn_area.py:214-275.  The black-box OCR itself is outside the path: its labels are the (fixed) ground truth."""
         crnn.train()
         prep.eval()
         prep.zero_grad()
         crnn.zero_grad()
         with torch.no_grad():
-            preds_all = prep(x)
-        preds, _, _ = sampler.query(preds_all, names, kA, names)
-        # all replicas in ONE Philox launch and ONE CRNN pass with per-replica-group BatchNorm
-        noisy, _ = noiser.batch(preds, replicas=inner_limit)
-        lpA = crnn(noisy, replica_groups=inner_limit)
-        lossA = ctc(lpA[:, (inner_limit - 1) * kA:, :], yA, insA, lensA)
-        lossA.backward()                             # area flow: last replica only
+            preds_all = prep(w.x)
+        if world > 1:                                # whole-minibatch ranking over the ranks (32 KB all-gather of the CERs)
+            preds, _, idx, kg = w.sampler.query_global(preds_all, w.names, w.k_global, w.names)
+            share = world * preds.shape[0] / kg
+        else:
+            preds, _, idx = w.sampler.query(preds_all, w.names, w.k_global, w.names)
+            share = 1.0
+        k = preds.shape[0]
+        if k:
+            # all replicas in ONE Philox launch and ONE CRNN pass with per-replica-group BatchNorm
+            noisy, _ = noiser.batch(preds, replicas=R)
+            lpA = crnn(noisy, replica_groups=R)
+            sel = idx.tolist()
+            yA = torch.cat([w.y[int(w.off[i]):int(w.off[i + 1])] for i in sel])
+            lossA = ctc(lpA[:, (R - 1) * k:, :], yA, torch.full((k,), 31, dtype=torch.int32), w.lens[idx.cpu()])
+            (lossA * share if share != 1.0 else lossA).backward()      # area flow: last replica only (SURVEY F6)
         if use_dist:
-            dist.all_reduce(fc.grad)
+            dist.all_reduce(fc.grad)                 # flat 35 MB CRNN gradient; the second all-reduce of the step (SURVEY F7)
             if world > 1:
                 fc.grad.mul_(1.0 / world)
         opt_c.step()
@@ -215,97 +295,135 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = fn()
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item(), out
+
+    W = Work(args.batch)
+    B = W.B
+
+    def full_step():
+        phase_a(W)
+        return phase_b(W)
+
+    main_step = (lambda: phase_b(W)) if args.phase_b_only else full_step
     for i in range(args.warmup):
-        step()
+        main_step()
         torch.cuda.synchronize()
         if rank == 0:
             print(f"[bench] warm-up {i + 1}/{args.warmup} done", file=sys.stderr, flush=True)
     # ---- timed region: the production configuration (weight gradients overlapped on a side stream), no event overhead
-    run = step
+    run = main_step
     if args.graph:
         from qea.graph import GraphedStep
-        run = GraphedStep(step, warmup=0)
+        run = GraphedStep(lambda: phase_b(W), warmup=0)
         run()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run()
-    fence()
-    dt = time.perf_counter() - t0
+    dt, loss = timed(run, args.steps)
     if rank == 0:
         print(f"[bench] {args.steps} timed steps in {dt:.3f}s", file=sys.stderr, flush=True)
+    # ---- Phase B alone at the same batch (the per-image unit of SURVEY.md §8d)
+    dt_b = dt
+    if not args.phase_b_only:
+        phase_b(W)
+        dt_b, _ = timed(lambda: phase_b(W), args.steps)
+
     # ---- roofline leg: the same K steps once more with the side stream off and every MFMA launch bracketed by HIP
     # events on its stream — with the overlap on, a launch's event-to-event time would include a co-running kernel
-    # (measured: 79 instead of 114 TFLOP/s), and the event records themselves cost the overlapped step 3 % (53.2 vs 51.6 ms)
-    overlap0 = ops.overlap_enabled()                 # QEA_OVERLAP=0 keeps the whole run single-stream (profiles/)
-    ops.set_overlap(False)
-    step()
-    for k in (ops.PROF_CONV_IGEMM, ops.PROF_CONV_WGRAD, ops.PROF_LSTM_STEP):
-        ops.prof_enable(k, True)
-    ops.prof_reset()
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt_serial = time.perf_counter() - t1
-    prof = {k: ops.prof_read(k) for k in (ops.PROF_CONV_IGEMM, ops.PROF_CONV_WGRAD, ops.PROF_LSTM_STEP)}
-    for k in prof:
-        ops.prof_enable(k, False)
-    ops.set_overlap(overlap0)
+    def event_leg(fn, steps):
+        overlap0 = ops.overlap_enabled()             # QEA_OVERLAP=0 keeps the whole run single-stream (profiles/)
+        ops.set_overlap(False)
+        fn()
+        for k in (ops.PROF_CONV_IGEMM, ops.PROF_CONV_WGRAD, ops.PROF_LSTM_STEP):
+            ops.prof_enable(k, True)
+        ops.prof_reset()
+        d, _ = timed(fn, steps)
+        prof = {k: ops.prof_read(k) for k in (ops.PROF_CONV_IGEMM, ops.PROF_CONV_WGRAD, ops.PROF_LSTM_STEP)}
+        for k in prof:
+            ops.prof_enable(k, False)
+        ops.set_overlap(overlap0)
+        return prof, d, overlap0
 
-    traffic = None                                   # HBM bytes per launch of the dominant kernel, from the committed PMC pass
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pm.get("batch_per_gpu") == B:
+    prof, dt_serial, overlap0 = event_leg(main_step, args.steps)
+    native = None
+    if not args.no_secondary:
+        # the same steps with every product on v_mfma_f32_32x32x2_f32: the class against the fp32 matrix peak
+        prev = ops.set_mfma_mode("f32")
+        try:
+            nsteps = max(2, min(args.steps, 4))
+            nprof, ndt, _ = event_leg(main_step, nsteps)
+            native = (nprof, ndt, nsteps)
+        finally:
+            ops.set_mfma_mode(prev)
+    c1 = None
+    if not args.no_secondary and B != 512:
+        W1 = Work(512)
+        for _ in range(2):
+            phase_b(W1)
+        d1, _ = timed(lambda: phase_b(W1), args.steps)
+        c1 = {"workload": "BASELINE configs[1]: Phase-B step, B = 512 per GPU", "value": 512 * world * args.steps / d1, "unit": "patch-images/s",
+              "ms_per_step": d1 / args.steps * 1e3}
+        del W1
+
+    traffic, traffic_note = None, "no PMC profile for this build"
+    try:                                             # HBM bytes per launch of the dominant class, from the committed PMC pass of THIS build
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        if pm.get("source_hash") != source_hash():
+            traffic_note = f"profiles/r02_pmc_traffic.json was taken on sources {pm.get('source_hash')} != this build {source_hash()}: refused"
+        elif pm.get("batch_per_gpu") != B or pm.get("full_step") != (not args.phase_b_only):
+            traffic_note = "profiles/r02_pmc_traffic.json was taken on another workload: refused"
+        else:
             traffic = pm["conv_igemm"]["hbm_bytes_per_launch"]
+            traffic_note = "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE in separate passes, profiles/r02_pmc_traffic.json (same sources)"
     except (OSError, KeyError, ValueError):
         pass
-    full = None
-    if args.full_step:
-        for _ in range(2):
-            phase_a()
-            step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            phase_a()
-            step()
-        fence()
-        dfull = time.perf_counter() - t1
-        tf = torch.tensor([dfull], device=dev)
-        if use_dist:
-            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-        full = {"value": B * world * args.steps / tf.item(), "unit": "patch-images/s", "ms_per_step": tf.item() / args.steps * 1e3,
-                "phase_a": {"selection": "topKCER", "minibatch_subset_prop": 0.95, "k_per_gpu": kA, "inner_limit": 4,
-                            "backward": "last replica (train_nn_area.py:269-271)", "replicas": "fused in the batch dim, per-group BN",
-                            "ocr": "fixed labels (black box excluded)"}}
-    tmax = torch.tensor([dt], device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+
     if rank == 0:
         ig, wg, ls = prof[ops.PROF_CONV_IGEMM], prof[ops.PROF_CONV_WGRAD], prof[ops.PROF_LSTM_STEP]
-        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        tf = lambda q: q["flops"] / (q["ms"] * 1e-3) / 1e12 if q["ms"] > 0 else 0.0
+        ach = tf(ig)
         # the class mixes split-bf16 launches (>= 128-channel layers) and native fp32-MFMA launches: its matrix roofline is
         # the flop-weighted harmonic blend of the two peaks (time at peak = flops_split / peak_split + flops_f32 / peak_f32)
+        blend = lambda q: 1.0 / ((q["flops_split_bf16"] / q["flops"]) / SPLIT_BF16_PEAK_TFLOPS
+                                 + (1.0 - q["flops_split_bf16"] / q["flops"]) / FP32_MFMA_PEAK_TFLOPS) if q["flops"] > 0 else FP32_MFMA_PEAK_TFLOPS
         f_split = ig["flops_split_bf16"] / ig["flops"] if ig["flops"] > 0 else 0.0
-        peak = 1.0 / (f_split / SPLIT_BF16_PEAK_TFLOPS + (1.0 - f_split) / FP32_MFMA_PEAK_TFLOPS)
-        wg_split = wg["flops_split_bf16"] / wg["flops"] if wg["flops"] > 0 else 0.0
+        peak = blend(ig)
+        imgs = B * world * args.steps
+        workload = ("BASELINE configs[2]: full minibatch step of train_nn_area.py:212-287 — Phase A (UNet eval fwd, TopKCER k = 5 % of the "
+                    f"minibatch, inner_limit = {R} jitter replicas fused in the batch dim, CRNN train-BN fwd+bwd, Adam(CRNN)) + Phase B (UNet "
+                    "train-BN -> CRNN BN-eval -> CTC mean + MSE -> backward -> Adam(UNet)) on synthetic POS-style 32x128 patches"
+                    if not args.phase_b_only else
+                    "Phase-B step (UNet train-BN -> CRNN BN-eval -> CTC mean + MSE -> backward -> Adam(UNet)) on synthetic POS-style 32x128 patches")
         out = {
             "metric": "patch-images/sec UNet->CRNN->CTC fwd+bwd, 32x128 grey",
-            "value": B * world * args.steps / dt,
+            "value": imgs / dt,
             "unit": "patch-images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if os.environ.get("QEA_MFMA") == "f32" else "f32 (>=128-channel GEMMs as 3 x bf16 split products, fp32 accumulate)",
+            "dtype": "f32" if ops.mfma_mode() == "f32" else "f32 (>=128-channel GEMMs as 3 x bf16 split products, fp32 accumulate)",
             "data": "synthetic",
             "overlap": {"wgrad_side_stream": overlap0, "ms_per_step_single_stream": dt_serial / args.steps * 1e3},
-            "config": {"workload": "Phase-B step (UNet train-BN -> CRNN BN-eval -> CTC mean + MSE -> backward -> Adam(UNet)) on "
-                                   "synthetic POS-style 32x128 patches, BASELINE configs[1] batch",
-                       "batch_per_gpu": B, "global_batch": B * world, "crnn_wgrad": not args.skip_crnn_wgrad,
-                       "parallelism": f"dp{world}", "loss": float(loss.item()), "hipgraph": bool(args.graph)},
+            "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * world, "full_step": not args.phase_b_only,
+                       "phase_a": None if args.phase_b_only else {
+                           "selection": "topKCER", "minibatch_subset_prop": 0.95, "k_global": W.k_global, "inner_limit": R,
+                           "ranking": "whole minibatch over the ranks (all-gather of the CERs)" if world > 1 else "whole minibatch",
+                           "backward": "last replica (train_nn_area.py:269-271)", "replicas": "fused in the batch dim, per-group BN",
+                           "ocr": "fixed labels (black box excluded)"},
+                       "crnn_wgrad": not args.skip_crnn_wgrad, "parallelism": f"dp{world}",
+                       "collectives_per_step": 0 if not use_dist else (1 if args.phase_b_only else 2),
+                       "loss": float(loss.item()), "hipgraph": bool(args.graph)},
+            "phase_b": {"value": imgs / dt_b, "unit": "patch-images/s", "ms_per_step": dt_b / args.steps * 1e3,
+                        "end_to_end_tflops": FLOP_PER_IMG_FAITHFUL * imgs / dt_b / 1e12 if not args.skip_crnn_wgrad else None,
+                        "note": "Phase B alone at the same batch: 9.846 GFLOP per image (SURVEY.md §8d unit of work)"},
             "roofline": {"bound": "mfma", "kernel": "qea_conv_igemm launches (implicit-GEMM conv fwd/dgrad, convT, LSTM/linear GEMMs): "
                                                       "conv_igemm_bf3_kernel = fp32 operands split into 3 bf16 planes, six "
                                                       "v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; conv_igemm_kernel / "
@@ -313,25 +431,31 @@ def main():
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "peak_note": f"fp32-equivalent; flop-weighted blend of bf16 dense peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} "
                                       f"({100 * f_split:.0f} % of the class's flops run split-bf16) and the fp32 MFMA peak "
-                                      f"{FP32_MFMA_PEAK_TFLOPS}; tools/micro/mfma_rate.hip sustains 1800 bf16 / 154.5 fp32 TFLOP/s on this "
-                                      "part, i.e. 300 fp32-equivalent for a pure split-bf16 loop",
+                                      f"{FP32_MFMA_PEAK_TFLOPS}",
                          "frac_of_native_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS, "split_bf16_flop_fraction": f_split,
                          "measured": "HIP events around every launch over the same K steps re-run with the wgrad side stream disabled "
                                      f"({dt_serial / args.steps * 1e3:.2f} ms/step single-stream vs {dt / args.steps * 1e3:.2f} overlapped)",
-                         "traffic": traffic, "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_pmc_traffic.json",
+                         "traffic": traffic, "traffic_note": traffic_note, "source_hash": source_hash(),
                          "algorithmic_bytes_per_launch": ig["bytes"] / max(1, ig["launches"]), "launches_per_step": ig["launches"] / args.steps,
                          "ms_per_step_in_kernel": ig["ms"] / args.steps},
             "kernels": {
-                "conv_wgrad": {"tflops": wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0, "ms_per_step": wg["ms"] / args.steps,
-                               "split_bf16_flop_fraction": wg_split,
+                "conv_wgrad": {"tflops": tf(wg), "ms_per_step": wg["ms"] / args.steps, "peak": blend(wg), "frac": tf(wg) / blend(wg),
+                               "split_bf16_flop_fraction": wg["flops_split_bf16"] / wg["flops"] if wg["flops"] > 0 else 0.0,
+                               "algorithmic_bytes_per_launch": wg["bytes"] / max(1, wg["launches"]),
                                "launches_per_step": wg["launches"] / args.steps},
-                "lstm_step": {"tflops": ls["flops"] / (ls["ms"] * 1e-3) / 1e12 if ls["ms"] > 0 else 0.0, "ms_per_step": ls["ms"] / args.steps,
-                              "launches_per_step": ls["launches"] / args.steps},
+                "lstm_step": {"tflops": tf(ls), "ms_per_step": ls["ms"] / args.steps, "launches_per_step": ls["launches"] / args.steps},
             },
-            "end_to_end_tflops": FLOP_PER_IMG_FAITHFUL * B * world * args.steps / dt / 1e12 if not args.skip_crnn_wgrad else None,
         }
-        if full is not None:
-            out["full_step"] = full
+        if native is not None:
+            nprof, ndt, nsteps = native
+            nig, nwg = nprof[ops.PROF_CONV_IGEMM], nprof[ops.PROF_CONV_WGRAD]
+            out["roofline"]["native_fp32"] = {
+                "note": "the same steps with every product on v_mfma_f32_32x32x2_f32 (qea_set_mfma_mode(QEA_MFMA_F32)), single stream, HIP events",
+                "conv_igemm_tflops": tf(nig), "peak": FP32_MFMA_PEAK_TFLOPS, "frac": tf(nig) / FP32_MFMA_PEAK_TFLOPS,
+                "conv_wgrad_tflops": tf(nwg), "conv_wgrad_frac": tf(nwg) / FP32_MFMA_PEAK_TFLOPS,
+                "ms_per_step_single_stream": ndt / nsteps * 1e3, "value": B * world * nsteps / ndt, "steps": nsteps}
+        if c1 is not None:
+            out["configs1_b512"] = c1
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -793,7 +793,9 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
       else if (d->R == 64 && d->C == 32) launch_halo<64, 32, 4>(d, h, hs);
       else launch_halo<64, 64, 2>(d, h, hs);
       reduce_slabs((float*)d->workspace, d->dw, (long long)slab / 4, h.grid * h.wk, d->accumulate, hs);
-      qea_prof_end(QEA_PROF_CONV_WGRAD, hs, 2.0 * d->B * d->PH * (double)d->PW * (double)slab, 0.0);
+      // algorithmic bytes: dY once + X once + dW once
+      qea_prof_end(QEA_PROF_CONV_WGRAD, hs, 2.0 * d->B * d->PH * (double)d->PW * (double)slab,
+                   4.0 * ((double)d->B * d->PH * d->PW * d->R + (double)d->B * d->QH * d->QW * d->C + (double)slab));
       QEA_CHECK_LAUNCH();
       return QEA_OK;
     }
@@ -835,7 +837,8 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     default: qea_set_error("qea_conv_wgrad: unknown tile %d", p.tile); return QEA_ERR_INVALID;
   }
   if (p.splits > 1) reduce_slabs((float*)d->workspace, d->dw, a.slab / 4, p.splits, d->accumulate, s);
-  qea_prof_end(QEA_PROF_CONV_WGRAD, s, 2.0 * a.M * (double)a.slab, 0.0, p.tile >= 20);
+  qea_prof_end(QEA_PROF_CONV_WGRAD, s, 2.0 * a.M * (double)a.slab,
+               4.0 * ((double)a.M * d->R + (double)d->B * d->QH * d->QW * d->C + (double)a.slab), p.tile >= 20);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

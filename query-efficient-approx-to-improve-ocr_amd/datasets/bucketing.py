@@ -48,10 +48,14 @@ class BucketBatchSampler(torch.utils.data.Sampler):
         return [out[i] for i in order]
 
     def __iter__(self):
-        return iter(self._batches())
+        from qea import dist as qdist
+        # under torch.distributed every rank draws the same global batch list (identical seeds) and takes every world-th batch
+        return iter(qdist.deal_batches(self._batches()))
 
     def __len__(self):
-        return len(self._batches())
+        from qea import dist as qdist
+        n = sum(len(idx) // self.batch_size if self.drop_last else -(-len(idx) // self.batch_size) for idx in self.groups.values())
+        return n // qdist.world()
 
 
 def bucket_collate(batch):

@@ -47,6 +47,8 @@ FLAGS = [
     ("--lr_scheduler", dict(choices=["cosine"], help="Learning-rate scheduler for the CRNN"), "a"),
     # ---- new (additive) ----
     ("--synthetic_size", dict(type=int, help="[new] train on N synthetic samples instead of reading --data_base_path"), "pa"),
+    ("--per_shard_topk", dict(action="store_true", help="[new] data-parallel runs only: pick the TopKCER subset per GPU shard instead of "
+                                                        "over the whole minibatch (not the reference's selection; saves one 32 KB all-gather)"), "a"),
 ]
 
 

@@ -50,8 +50,9 @@ def allreduce_module_grads(module):
         allreduce_mean_(fs.grad)
         return
     for p in module.parameters():
-        if p.grad is not None:
-            allreduce_mean_(p.grad)
+        if p.grad is None:                                      # a rank without work this step still joins every collective
+            p.grad = torch.zeros_like(p)
+        allreduce_mean_(p.grad)
 
 
 def global_topk(local_cers, k_global):
@@ -80,3 +81,24 @@ def global_topk(local_cers, k_global):
     start = sum(sizes[:r])
     mine = order[(order >= start) & (order < start + sizes[r])] - start
     return mine, k_global
+
+
+def equal_shards(indices, per_step):
+    """Shard a (rank-identical) index list so that EVERY rank gets the same number of optimiser steps: the list is cut to a
+    multiple of world * per_step and step i of rank r takes the r-th group of `per_step` indices of the i-th global batch.
+    Ranks that ran different step counts would leave the others blocked in their next all-reduce."""
+    w, r = world(), rank()
+    if w == 1:
+        return indices
+    idx = torch.as_tensor(indices)
+    steps = idx.numel() // (w * per_step)
+    return idx[: steps * w * per_step].view(steps, w, per_step)[:, r].reshape(-1)
+
+
+def deal_batches(batches):
+    """Round-robin deal of a (rank-identical) list of batches, cut to a multiple of the world size."""
+    w, r = world(), rank()
+    if w == 1:
+        return batches
+    n = len(batches) // w * w
+    return batches[:n][r::w]

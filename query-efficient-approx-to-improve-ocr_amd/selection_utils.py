@@ -103,6 +103,16 @@ class TopKCERSampler(DataSampler):
         idx = _desc_stable_topk(_known(names, self.cers), num_samples, images.device if torch.is_tensor(images) else None)
         return self._take(images, labels, idx)
 
+    def query_global(self, images, labels, num_samples_global, names):
+        """Data-parallel form: the reference ranks the WHOLE minibatch (train_nn_area.py:220-225); here the minibatch is sharded
+        over the ranks, so the shards' CERs are all-gathered (qea.dist.global_topk: stable descending order, rank-major index
+        as the tie-break = the single-process order of the concatenated minibatch) and each rank keeps the winners that live
+        in its shard — possibly none.  Returns (images_sel, labels_sel, idx, k_global)."""
+        from qea import dist as qdist
+        mine, k_global = qdist.global_topk(_known(names, self.cers), num_samples_global)
+        imgs, labs, idx = self._take(images, labels, mine)
+        return imgs, labs, idx, k_global
+
 
 class UniformEntropySampler(DataSampler):
     def __init__(self, entropies, cers):

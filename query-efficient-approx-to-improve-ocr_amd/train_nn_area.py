@@ -18,6 +18,7 @@ import os
 import torch
 
 import properties
+from qea import dist as qdist
 from qea.trainer_core import TrainerCore
 from tracking_utils import add_labels_to_history, call_crnn, generate_ctc_target_batches, weighted_ctc_loss
 from transform_helper import AddGaussianNoice
@@ -39,15 +40,19 @@ class TrainNNPrep(TrainerCore):
         if not self.val_subset_size:
             self.val_subset_size = len(val_set)
         tr_idx = torch.randperm(len(train_set))[: self.train_subset_size]
-        if self.world > 1:                                    # shard the (identically seeded) permutation
-            tr_idx = tr_idx[self.rank::self.world]
         widths = getattr(train_set, "widths", None)
+        self.per_shard_topk = bool(getattr(args, "per_shard_topk", False))
         if widths is not None:                                # [new] variable-width lines: one width bucket per batch
+            # the bucket batches are formed over the WHOLE (rank-identical) list and dealt round-robin, so every rank
+            # runs the same number of steps (qea.dist.deal_batches)
             from datasets.bucketing import BucketBatchSampler, bucket_collate
             sub = torch.utils.data.Subset(train_set, tr_idx.tolist())
             self.loader_train = torch.utils.data.DataLoader(
                 sub, collate_fn=bucket_collate, batch_sampler=BucketBatchSampler([widths[i] for i in tr_idx.tolist()], self.batch_size))
         else:
+            # data parallel: cut the (identically seeded) permutation to whole global batches, one group of batch_size per rank
+            # and step: every rank runs the same number of optimiser steps (a rank with fewer would strand the others in RCCL)
+            tr_idx = qdist.equal_shards(tr_idx, self.batch_size)
             self.loader_train = torch.utils.data.DataLoader(train_set, batch_size=self.batch_size, drop_last=True,
                                                             sampler=torch.utils.data.SubsetRandomSampler(tr_idx))
         va_idx = torch.randperm(len(val_set))[: self.val_subset_size]
@@ -85,9 +90,17 @@ class TrainNNPrep(TrainerCore):
                 self._set_phase_a()
                 with torch.no_grad():
                     img_preds_all = self.prep_model(X_var)
+                share = 1.0                                      # this rank's weight in the data-parallel mean of Phase A
                 if self.selection_method and epoch >= self.warmup_epochs:
-                    k = self._num_bb_samples(img_preds_all.shape[0])
-                    img_preds, labels_gt, bb_idx = self.sampler.query(img_preds_all, labels, k, names)
+                    if self.world > 1 and not self.per_shard_topk and hasattr(self.sampler, "query_global"):
+                        # whole-minibatch TopKCER over the shards (train_nn_area.py:220-225 ranks the whole minibatch); the
+                        # averaged gradient equals the global-batch mean when rank r weighs its mean loss by world * n_r / k
+                        k = self._num_bb_samples(img_preds_all.shape[0] * self.world)
+                        img_preds, labels_gt, bb_idx, k = self.sampler.query_global(img_preds_all, labels, k, names)
+                        share = self.world * img_preds.shape[0] / max(1, k)
+                    else:
+                        k = self._num_bb_samples(img_preds_all.shape[0])
+                        img_preds, labels_gt, bb_idx = self.sampler.query(img_preds_all, labels, k, names)
                     img_preds = img_preds.detach()
                     img_preds_names = [names[i] for i in bb_idx.tolist()]
                     for name in img_preds_names:
@@ -97,7 +110,11 @@ class TrainNNPrep(TrainerCore):
                     img_preds, img_preds_names = img_preds_all.detach(), names
                 loss = None
                 n_skip = 1 if (self.inner_limit_skip and self.inner_limit > 0) else 0
-                if n_skip:                                       # iteration 0 without noise: label tracking (:247-259)
+                if img_preds.shape[0] == 0:                      # data parallel: none of the global winners lives in this shard
+                    if self.inner_limit:
+                        self._step_crnn()                        # still joins the all-reduce (with zero gradients)
+                    n_skip = -1
+                if n_skip > 0:                                   # iteration 0 without noise: label tracking (:247-259)
                     ocr_labels = self.ocr.get_labels(img_preds.cpu())
                     loss_weights = self.loss_wghts_gnrtr.gen_weights(self.tracked_labels, img_preds_names)
                     add_labels_to_history(self, img_preds_names, ocr_labels)
@@ -106,15 +123,16 @@ class TrainNNPrep(TrainerCore):
                     loss = weighted_ctc_loss(self, scores, pred_size, target_batches, loss_weights)
                     total_bb_calls += len(ocr_labels)
                     epoch_bb_calls += len(ocr_labels)
-                rep_losses, calls = self._replica_losses(img_preds, noiser, self.inner_limit - n_skip)
-                total_bb_calls += calls
-                epoch_bb_calls += calls
-                if rep_losses:
-                    loss = rep_losses[-1]
-                if self.inner_limit:
-                    CRNN_training_loss = loss.item() / max(1, self.inner_limit)
-                    loss.backward()                              # the last replica only, as the reference (:269-271)
-                    self._step_crnn()
+                if n_skip >= 0:
+                    rep_losses, calls = self._replica_losses(img_preds, noiser, self.inner_limit - n_skip)
+                    total_bb_calls += calls
+                    epoch_bb_calls += calls
+                    if rep_losses:
+                        loss = rep_losses[-1]
+                    if self.inner_limit:
+                        CRNN_training_loss = loss.item() / max(1, self.inner_limit)
+                        (loss * share if share != 1.0 else loss).backward()   # the last replica only, as the reference (:269-271)
+                        self._step_crnn()
                 # ---------------- Phase B ----------------
                 self._set_phase_b()
                 img_preds = self.prep_model(X_var)

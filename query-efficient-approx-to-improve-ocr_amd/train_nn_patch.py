@@ -16,6 +16,7 @@ import os
 import torch
 
 import properties
+from qea import dist as qdist
 from qea.trainer_core import TrainerCore
 from tracking_utils import add_labels_to_history, call_crnn, generate_ctc_target_batches, weighted_ctc_loss
 from transform_helper import AddGaussianNoice
@@ -45,8 +46,8 @@ class TrainNNPrep(TrainerCore):
         if not self.val_subset_size:
             self.val_subset_size = len(val_set)
         idx = torch.randperm(len(train_set))[: self.train_subset_size]
-        if self.world > 1:
-            idx = idx[self.rank::self.world]
+        idx = qdist.equal_shards(idx, 1)                        # data parallel: the same number of documents (= steps) on every rank
+        self._train_idx = idx
         self._collate = collate
         self.loader_train = torch.utils.data.DataLoader(train_set, batch_size=1, drop_last=True, collate_fn=collate,
                                                         sampler=torch.utils.data.SubsetRandomSampler(idx))
@@ -78,7 +79,9 @@ class TrainNNPrep(TrainerCore):
                 self.sampler.select_samples()
             training_loss, epoch_bb_calls, CRNN_training_loss = 0.0, 0, 0.0
             if self.num_subset_images:
-                sub = torch.randperm(self.train_set_size)[: self.num_subset_images]
+                # a fresh subset of THIS rank's documents per epoch (train_nn_patch.py:209-218); the draw is rank-identical
+                # and every shard has the same length, so the step counts stay equal
+                sub = self._train_idx[torch.randperm(self.train_set_size)[: self.num_subset_images]]
                 self.loader_train = torch.utils.data.DataLoader(self.dataset, batch_size=1, drop_last=True, collate_fn=self._collate,
                                                                 sampler=torch.utils.data.SubsetRandomSampler(sub))
             for images, labels_dicts, names in self.loader_train:

@@ -587,51 +587,70 @@ def _candidate_ok(R, x, labels, labels_a):
     return True, figs
 
 
+N_S64 = 128     # fp64 samples kept per gradient tensor (the full tensors come from the pinned oracle at test time)
+
+
+def sample_index_small(n):
+    if n <= N_S64:
+        return torch.arange(n)
+    return torch.randperm(n, generator=torch.Generator().manual_seed(4321 + n))[:N_S64]
+
+
 def full64(named_params64, prefix, out):
-    """Per tensor of the fp64 reference run: |s64 (values at sample_index), |l264, |sum64, |abs64."""
+    """Per tensor of the fp64 reference run: |s64 (values at sample_index_small), |l264, |sum64."""
     for name, p in named_params64:
         g64 = p.grad.detach().double().flatten()
-        out[f"{prefix}{name}|s64"] = g64[sample_index(g64.numel())].numpy().copy()
+        out[f"{prefix}{name}|s64"] = g64[sample_index_small(g64.numel())].numpy().copy()
         out[f"{prefix}{name}|l264"] = g64.norm().item()
         out[f"{prefix}{name}|sum64"] = g64.sum().item()
-        out[f"{prefix}{name}|abs64"] = g64.abs().sum().item()
+
+
+COND_SHAPES = ((2, 32, 50, 1000, 6), (4, 64, 54, 4000, 6), (4, 128, 56, 3000, 4))   # B, W, weight seed, first image seed, candidates kept
 
 
 def make_conditioned():
-    """tests/golden/cond_b2w32.npz, cond_b4w64.npz, cond_b4w128.npz: for each shape the FIRST image seed (fixed weight seed, fixed seed
-    order) that passes _candidate_ok; the rejected seeds and their figures are stored with it."""
-    for B, W, ws, xs0 in ((2, 32, 50, 1000), (4, 64, 54, 4000), (4, 128, 56, 3000)):
+    """tests/golden/cond_b2w32.npz, cond_b4w64.npz, cond_b4w128.npz: for each shape the first K image seeds (fixed weight
+    seed, fixed seed order) that pass _candidate_ok, stored as candidates c0..c{K-1}; the rejected seeds and their figures
+    are stored with them.  Several candidates per shape, because passing nine evaluations of ATen's fp32 kernels does not
+    make a candidate flip-free for ANOTHER fp32 implementation (its roundings fall elsewhere): the GPU tests state their
+    requirement over the candidate set (tests/test_conditioned_gpu.py)."""
+    for B, W, ws, xs0, keep in COND_SHAPES:
         T = W // 4 - 1
         R = RefRunner(ws)
-        log = []
-        for xs in range(xs0, xs0 + 600):
+        log, out, k = [], {}, 0
+        for xs in range(xs0, xs0 + 2000):
             x = torch.rand(B, 1, 32, W, generator=torch.Generator().manual_seed(xs))
             labels = synth_labels(B, xs, 1, max(1, T // 2))
             labels_a = synth_labels(B, xs + 100, 1, max(1, T // 2))
             ok, figs = _candidate_ok(R, x, labels, labels_a)
             log.append(f"{xs}:{'ok' if ok else 'rejected'}:{figs}")
-            if ok:
+            if not ok:
+                continue
+            c = f"c{k}|"
+            print(f"cond B={B} W={W}: candidate {k} = image seed {xs} ({len(log) - k - 1} rejections so far); fp32 variants vs fp64: max {max(figs.values()):.2e}", flush=True)
+            out.update({c + "x": x.numpy(), c + "labels": np.array(labels), c + "labels_a": np.array(labels_a), c + "xs": xs,
+                        c + "variant_worst": np.array([figs[v] for v in FP32_VARIANTS])})
+            b64 = R.phase_b(torch.float64, x, labels)
+            full64(b64["prep"].named_parameters(), c + "B|g|prep|", out)
+            full64(b64["crnn"].named_parameters(), c + "B|g|crnn|", out)
+            out.update({c + "B|loss64": b64["loss"], c + "B|img64": b64["img"].numpy(), c + "B|lp64": b64["lp"].numpy(),
+                        c + "B|loss32": R.phase_b(torch.float32, x, labels)["loss"]})
+            for kk, v in b64["prep"].state_dict().items():
+                if mo.is_buffer(kk) and v.is_floating_point():
+                    out[f"{c}B|buf|{kk}"] = v.numpy().copy()
+            a64 = R.phase_a(torch.float64, x, labels_a)
+            full64(a64["crnn"].named_parameters(), c + "A|g|", out)
+            out.update({c + "A|loss64": a64["loss"], c + "A|lp64": a64["lp"].numpy(), c + "A|dx64": a64["dx"].numpy(),
+                        c + "A|loss32": R.phase_a(torch.float32, x, labels_a)["loss"]})
+            for kk, v in a64["crnn"].state_dict().items():
+                if mo.is_buffer(kk) and v.is_floating_point():
+                    out[f"{c}A|buf|{kk}"] = v.numpy().copy()
+            k += 1
+            if k == keep:
                 break
         else:
-            raise SystemExit(f"B={B} W={W}: no knife-edge-free candidate in 600 seeds")
-        print(f"cond B={B} W={W}: accepted image seed {xs} after {len(log) - 1} rejections; fp32 variants vs fp64: {figs}")
-        out = {"x": x.numpy(), "labels": np.array(labels), "labels_a": np.array(labels_a), "ws": ws, "xs": xs, "W": W, "B": B,
-               "search_log": np.array(log), "variant_worst": np.array([figs[v] for v in FP32_VARIANTS])}
-        b64 = R.phase_b(torch.float64, x, labels)
-        full64(b64["prep"].named_parameters(), "B|g|prep|", out)
-        full64(b64["crnn"].named_parameters(), "B|g|crnn|", out)
-        out.update({"B|loss64": b64["loss"], "B|img64": b64["img"].numpy(), "B|lp64": b64["lp"].numpy(),
-                    "B|loss32": R.phase_b(torch.float32, x, labels)["loss"]})
-        for k, v in b64["prep"].state_dict().items():
-            if mo.is_buffer(k) and v.is_floating_point():
-                out[f"B|buf|{k}"] = v.numpy().copy()
-        a64 = R.phase_a(torch.float64, x, labels_a)
-        full64(a64["crnn"].named_parameters(), "A|g|", out)
-        out.update({"A|loss64": a64["loss"], "A|lp64": a64["lp"].numpy(), "A|dx64": a64["dx"].numpy(),
-                    "A|loss32": R.phase_a(torch.float32, x, labels_a)["loss"]})
-        for k, v in a64["crnn"].state_dict().items():
-            if mo.is_buffer(k) and v.is_floating_point():
-                out[f"A|buf|{k}"] = v.numpy().copy()
+            raise SystemExit(f"B={B} W={W}: fewer than {keep} knife-edge-free candidates in 2000 seeds")
+        out.update({"ws": ws, "W": W, "B": B, "n_candidates": keep, "search_log": np.array(log)})
         np.savez_compressed(os.path.join(HERE, f"cond_b{B}w{W}.npz"), **out)
 
 
@@ -726,7 +745,8 @@ def make_tracking():
     tracking_utils.py (imported unchanged) and DecayingWeightGenerator (label_tracking/tracking_methods.py:105-115,
     compiled from the reference file: the module needs the absent python-Levenshtein): a 3-epoch OCR-label history with
     ragged depth per strip, window 3, decay 0.7 -> generate_ctc_target_batches -> weighted_ctc_loss on the reference CRNN
-    (train-mode BN), loss + every CRNN gradient in fp32 and fp64."""
+    (train-mode BN), loss + every CRNN gradient in fp64.  Four image candidates c0..c3 (first seeds whose fp32 run agrees with
+    the fp64 run to COND_MAX on every tensor), same history for all."""
     import abc
     import types
     import tracking_utils as rtu                                 # reference, root module
@@ -736,14 +756,14 @@ def make_tracking():
     ns = {"torch": torch, "ABCMeta": abc.ABCMeta, "abstractmethod": abc.abstractmethod}
     exec(compile(ast.Module(body=body, type_ignores=[]), "tracking_methods.py", "exec"), ns)
     out = {}
-    B, ws, window, decay = 6, 40, 3, 0.7
-    x = torch.rand(B, 1, 32, 128, generator=torch.Generator().manual_seed(51))
+    B, ws, window, decay, keep = 6, 40, 3, 0.7, 4
     names = [f"s{i}" for i in range(B)]
     hist = [synth_labels(B, 60 + e, 1, 9) for e in range(3)]     # epoch 0, 1, 2 OCR labels
     depth = [3, 1, 2, 3, 0, 2]                                   # how many past epochs each strip was queried in (0: new now)
     c2i = {c: i for i, c in enumerate(properties.char_set)}
-    runs = {}
-    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+    current = synth_labels(B, 70, 1, 9)                          # this iteration's OCR labels
+
+    def run(dt, x):
         _, crnn = _ref_models(ws, dt)
         crnn.train()
         self = types.SimpleNamespace(device=torch.device("cpu"), crnn_model=crnn, char_to_index=c2i, window_size=window,
@@ -751,23 +771,31 @@ def make_tracking():
                                      primary_loss_fn_sample_wise=torch.nn.CTCLoss(reduction="none"),
                                      tracked_labels={n: [hist[e][i] for e in range(3)][:depth[i]] for i, n in enumerate(names)})
         wg = ns["DecayingWeightGenerator"](types.SimpleNamespace(decay_factor=decay, window_size=window), self.device)
-        current = synth_labels(B, 70, 1, 9)                      # this iteration's OCR labels
         loss_weights = wg.gen_weights(self.tracked_labels, names)
         rtu.add_labels_to_history(self, names, current)
         batches = rtu.generate_ctc_target_batches(self, names)
         scores, pred_size = rtu.call_crnn(self, x.to(dt))
         loss = rtu.weighted_ctc_loss(self, scores, pred_size, batches, loss_weights)
         loss.backward()
-        runs[tag] = (crnn, loss.item(), scores.detach(), batches, loss_weights, self.tracked_labels)
-    crnn32, l32, _, batches, lw, tracked = runs["32"]
-    crnn64, l64, sc64, _, _, _ = runs["64"]
-    full64(crnn64.named_parameters(), "g|", out)
-    out["dev32"] = _worst_rel(_grads(crnn32.named_parameters()), _grads(crnn64.named_parameters()), skip=ZERO_GRAD)
-    out.update({"x": x.numpy(), "loss32": l32, "loss64": l64, "lp64": sc64.numpy(), "weights": lw.numpy(), "window": window, "decay": decay,
-                "ws": ws, "names": np.array(names), "current": np.array(current),
+        return crnn, loss.item(), scores.detach(), batches, loss_weights, self.tracked_labels
+
+    k, xs = 0, 5100
+    while k < keep:
+        x = torch.rand(B, 1, 32, 128, generator=torch.Generator().manual_seed(xs))
+        crnn32, l32, _, batches, lw, tracked = run(torch.float32, x)
+        crnn64, l64, sc64, _, _, _ = run(torch.float64, x)
+        dev = _worst_rel(_grads(crnn32.named_parameters()), _grads(crnn64.named_parameters()), skip=ZERO_GRAD)
+        print("tracking candidate seed", xs, "fp32 vs fp64", dev)
+        xs += 1
+        if dev > COND_MAX:
+            continue
+        c = f"c{k}|"
+        full64(crnn64.named_parameters(), c + "g|", out)
+        out.update({c + "x": x.numpy(), c + "loss32": l32, c + "loss64": l64, c + "lp64": sc64.numpy(), c + "dev32": dev, c + "xs": xs - 1})
+        k += 1
+    out.update({"weights": lw.numpy(), "window": window, "decay": decay, "ws": ws, "names": np.array(names), "current": np.array(current),
                 "history_json": np.array(json.dumps({n: [hist[e][i] for e in range(3)][:depth[i]] for i, n in enumerate(names)})),
-                "tracked_after_json": np.array(json.dumps(tracked)),
-                "n_batches": len(batches)})
+                "tracked_after_json": np.array(json.dumps(tracked)), "n_batches": len(batches), "n_candidates": keep})
     for i, (t, ts, idx) in enumerate(batches):
         out[f"batch{i}|target"], out[f"batch{i}|size"], out[f"batch{i}|idx"] = t.numpy(), ts.numpy(), np.array(idx)
     np.savez_compressed(os.path.join(HERE, "tracking_b6.npz"), **out)

@@ -149,13 +149,21 @@ def _state64(shapes, seed):
     return {k: (v.double() if v.is_floating_point() else v) for k, v in mo.default_init_state(shapes, seed).items()}
 
 
-def oracle_cond_case(fx):
-    """-> (Phase-B result, Phase-A result) of the CPU oracle in fp64: losses, activations, FULL gradient tensors."""
+def sample_index_small(n, keep=128):
+    """Same subset rule as tests/golden/make_golden.py::sample_index_small (round-2 fixtures)."""
+    if n <= keep:
+        return torch.arange(n)
+    return torch.randperm(n, generator=torch.Generator().manual_seed(4321 + n))[:keep]
+
+
+def oracle_cond_case(fx, c=""):
+    """-> (Phase-B result, Phase-A result) of the CPU oracle in fp64 on candidate `c` ("c0|", ...) of a cond_b*.npz pack:
+    losses, activations, FULL gradient tensors."""
     import torch.nn.functional as F
     from oracle import model_oracle as mo
     ws = int(fx["ws"])
-    x = torch.from_numpy(fx["x"]).double()
-    labels, labels_a = [str(s) for s in fx["labels"]], [str(s) for s in fx["labels_a"]]
+    x = torch.from_numpy(fx[c + "x"]).double()
+    labels, labels_a = [str(s) for s in fx[c + "labels"]], [str(s) for s in fx[c + "labels_a"]]
     Pu, Bu = mo.split_state(_state64(mo.unet_state_shapes(), ws))
     Pc, Bc = mo.split_state(_state64(mo.crnn_state_shapes(), ws + 1))
     img = mo.unet_forward(Pu, Bu, x, training=True)
@@ -176,12 +184,12 @@ def oracle_cond_case(fx):
     return rB, rA
 
 
-def oracle_tracking_case(fx, batches, weights):
+def oracle_tracking_case(fx, batches, weights, c="c0|"):
     """weighted_ctc_loss (tracking_utils.py:59-75, decaying weights) on the oracle CRNN (train-mode BN), fp64."""
     import torch.nn.functional as F
     from oracle import model_oracle as mo
     Pc, Bc = mo.split_state(_state64(mo.crnn_state_shapes(), int(fx["ws"]) + 1))
-    x = torch.from_numpy(fx["x"]).double()
+    x = torch.from_numpy(fx[c + "x"]).double()
     lp = mo.crnn_forward(Pc, Bc, x, bn_training=True)
     total = 0
     for i, (t, ts, idx) in enumerate(batches):

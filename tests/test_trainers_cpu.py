@@ -102,10 +102,18 @@ def _dp_worker(rank, world, port, tmp, out):
     from ocr_helper.stub_helper import StubHelper
     from qea import dist as qdist
     from train_nn_area import TrainNNPrep
-    args = _args("a", os.path.join(tmp, f"exp{rank}"), batch_size=2, inner_limit=1)
-    t = TrainNNPrep(args, backend=oracle_backend(), train_set=SyntheticTextAreas(4, seed=1, include_name=True, include_index=True),
-                    val_set=SyntheticTextAreas(2, seed=2, include_name=True), ocr=StubHelper())
+    # 7 samples on 2 ranks x batch 2: NOT divisible — every rank must still run the same number of steps;
+    # TopKCER with prop 0.5 picks k = 2 of each GLOBAL batch of 4 (train_nn_area.py:220-225 ranks the whole minibatch)
+    tr_set = SyntheticTextAreas(7, seed=1, include_name=True, include_index=True)
+    cers = {n: c for n, c in zip(tr_set.names, [0.30, 0.90, 0.10, 0.70, 0.20, 0.80, 0.40])}
+    cers_path = os.path.join(tmp, f"cers{rank}.json")
+    json.dump(cers, open(cers_path, "w"))
+    args = _args("a", os.path.join(tmp, f"exp{rank}"), batch_size=2, inner_limit=1, minibatch_subset="topKCER", minibatch_subset_prop=0.5,
+                 cers_ocr_path=cers_path)
+    t = TrainNNPrep(args, backend=oracle_backend(), train_set=tr_set, val_set=SyntheticTextAreas(2, seed=2, include_name=True), ocr=StubHelper())
     assert t.world == world
+    shard = sorted(tr_set.names[i] for batch in t.loader_train.sampler for i in [batch])
+    assert len(t.loader_train) == 1 and len(shard) == 2
     # gradient exchange == mean of the shard gradients (checked by the parent): one Phase-B backward on a rank-specific shard
     x = H.synth_images(2, 100 + rank)
     t._set_phase_b()
@@ -118,7 +126,9 @@ def _dp_worker(rank, world, port, tmp, out):
     t.train()
     mine, k = qdist.global_topk([0.1 * (rank + 1), 0.9 - 0.5 * rank, 0.3], 3)
     flat = torch.cat([p.detach().flatten() for p in t.prep_model.parameters()] + [p.detach().flatten() for p in t.crnn_model.parameters()])
-    torch.save({"flat": flat, "topk": mine, "local": local, "reduced": reduced}, os.path.join(out, f"r{rank}.pt"))
+    picked = sorted(n for n, v in t.selected_samples.items() if v[0])
+    torch.save({"flat": flat, "topk": mine, "local": local, "reduced": reduced, "shard": shard, "picked": picked, "cers0": cers},
+               os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -134,3 +144,29 @@ def test_data_parallel_gloo_world2(tmp_path):
     assert torch.equal(r0["reduced"], r1["reduced"])
     assert torch.allclose(r0["reduced"], (r0["local"] + r1["local"]) / 2, rtol=1e-6, atol=1e-9)
     assert not torch.equal(r0["local"], r1["local"])
+    # whole-minibatch selection under DP == the single-process selection over the concatenated minibatch
+    assert not set(r0["shard"]) & set(r1["shard"])
+    batch = r0["shard"] + r1["shard"]
+    want = sorted(sorted(batch, key=lambda n: -r0["cers0"][n])[:2])
+    assert sorted(r0["picked"] + r1["picked"]) == want, (r0["picked"], r1["picked"], want)
+    assert set(r0["picked"]) <= set(r0["shard"]) and set(r1["picked"]) <= set(r1["shard"])
+
+
+def test_equal_shards_give_every_rank_the_same_step_count(monkeypatch):
+    """qea.dist.equal_shards / deal_batches: any dataset size, any world size -> identical step counts, disjoint shards."""
+    from qea import dist as qdist
+    for n, w, bs in ((10, 4, 1), (255, 2, 64), (7, 2, 2), (1000, 8, 32), (3, 4, 1)):
+        shards = []
+        for r in range(w):
+            monkeypatch.setattr(qdist, "world", lambda w=w: w)
+            monkeypatch.setattr(qdist, "rank", lambda r=r: r)
+            shards.append(qdist.equal_shards(torch.arange(n), bs).tolist())
+        assert len({len(s) for s in shards}) == 1 and len(shards[0]) == n // (w * bs) * bs
+        flat = [i for s in shards for i in s]
+        assert len(set(flat)) == len(flat)
+        batches = [[i] for i in range(n)]
+        dealt = []
+        for r in range(w):
+            monkeypatch.setattr(qdist, "rank", lambda r=r: r)
+            dealt.append(qdist.deal_batches(batches))
+        assert len({len(d) for d in dealt}) == 1
