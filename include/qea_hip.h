@@ -98,9 +98,24 @@ typedef struct qea_conv_desc {
   int32_t accumulate; /* 0/1                                                              */
   int32_t out_mode;   /* QEA_OUT_*                                                        */
   int32_t tile;       /* 0 = auto; else forced tile config id (tests / tuning)            */
+  /* ABI v2: optional PRE-SPLIT operands of the split-bf16 tiles (NULL: split on the fly).  Both in the P3 format written
+   * by qea_split_planes: x_planes from x (M = B*H*W rows, Cin channels), w_planes from w (N rows, K = KH*KW*Cin).   */
+  const void* x_planes;
+  const void* w_planes;
 } qea_conv_desc;
 
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
+/* 1 when qea_conv_igemm would run this launch on a split-bf16 tile (so that pre-split operands pay), else 0 */
+int qea_conv_igemm_uses_split_bf16(const qea_conv_desc* d);
+
+/* P3 format of a fp32 matrix [M][ld] with C used columns (C % 16 == 0): planes[row][C/16][3][16] bf16 — per 16-column
+ * slice the three bf16 planes h, m, l of x = h + m + l (|x - (h+m+l)| <= 2^-24 |x|), 96 contiguous bytes — followed by
+ * a 128-byte zero tail (the source of out-of-image taps).  One HBM pass: 4 B read + 6 B written per element, against
+ * ~5.5 VALU operations per element for EVERY tap and N-tile when the conv kernel splits on the fly.  Used for the
+ * activations / gradients entering nn.Conv2d forward, input-gradient (models/model_unet.py:78-109,
+ * models/model_crnn.py:38-45) and for their filters. */
+size_t qea_split_planes_bytes(int64_t M, int32_t C);
+int qea_split_planes(const float* x, int32_t ld, int64_t M, int32_t C, void* planes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight gradient on the matrix cores (fp32 MFMA, or the split-bf16 form of qea_conv_igemm for R, C >= 64 with one

@@ -13,6 +13,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -26,6 +27,10 @@ struct ConvArgs {
   int B, H, W, Cin, OH, OW, N, KH, KW, pad_h, pad_w, stride_h, stride_w;
   int ldx, ldy, ldmask, relu, accumulate, out_mode;
   int M, K, n_tiles, m_tiles;
+  // pre-split operands (P3 format, see qea_split_planes): byte pointers + the byte offset of each buffer's zero chunk
+  const char* xp;
+  const char* wp;
+  unsigned xp_zero, wp_zero;
 };
 
 // Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,
@@ -95,8 +100,8 @@ struct IgemmGather {
   int lrow, kc, ntaps;
   int a_pix[A_LD];             // b*H*W, or -1 when the row is past M
   int a_ih0[A_LD], a_iw0[A_LD];
-  const float* b_ptr[B_LD];    // filter row of slot j (+ kc*4), or null past N
-  f32x4 a_reg[A_LD], b_reg[B_LD];
+  const float* b_ptr[B_LD > 0 ? B_LD : 1];    // filter row of slot j (+ kc*4), or null past N
+  f32x4 a_reg[A_LD], b_reg[B_LD > 0 ? B_LD : 1];
 
   __device__ __forceinline__ void init(const ConvArgs& p, int tid, int m0, int n0) {
     constexpr int KCH = BK / 4;
@@ -372,6 +377,699 @@ void conv_igemm_bf3_kernel(const ConvArgs p) {
   conv_epilogue<MI, NJ, TM, TN>(p, acc, m0, n0, wm, wn, fr, fh);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The split-bf16 implicit GEMM on PRE-SPLIT operands ("P3" format, written once per tensor by split_planes_kernel):
+//   planes[row][C/16][3][16]  bf16 — for every 16-channel slice of a pixel (or of a filter row) the h, m, l planes side by
+//   side, 96 contiguous bytes.
+// conv_igemm_bf3_kernel splits every gathered fp32 element again for each of the 9 taps and each N-tile that uses it
+// (~5.5 VALU operations per element and stage: the PMC pass showed the loop bound by instruction issue, matrix pipe 47 %
+// busy).  Here a K stage is pure data movement: every wave issues its share of 1 KiB LDS-DMA pieces (global_load_lds_dwordx4:
+// 32 rows x 32 bytes of ONE plane per wave-instruction, per-lane source address = the im2col gather; lanes of rows outside
+// the image / past M or N read a zero chunk kept behind the planes), no VGPR staging, no conversions, no ds_write.
+// The LDS image, the fragment reads and the MFMA sequence are those of conv_igemm_bf3_kernel, so the results are
+// bit-identical to it (tests/test_conv_igemm_gpu.py::test_presplit_planes_bit_identical).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void qea_lds_void;
+typedef __attribute__((address_space(1))) const void qea_glob_void;
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(WGM * WGN == 8 ? 4 : 1)))
+void conv_igemm_p3_kernel(const ConvArgs p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int ROWB = 16;                     // bf16 per LDS row (32 bytes); halves of rows 8..15 (mod 16) swapped, as in bf3
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MI = TM / 32, NJ = TN / 32;
+  constexpr int NA = 3 * BM / 32, NB = 3 * BN / 32;            // 1 KiB DMA pieces per stage (A, B)
+  constexpr int IA = (NA + NW - 1) / NW, IB = (NB + NW - 1) / NW;   // per wave
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem);  // [2][3][BM][ROWB]
+  __bf16* Bs = As + 2 * 3 * BM * ROWB;           // [2][3][BN][ROWB]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nwg = p.m_tiles * p.n_tiles;
+  const int tile = qea_xcd_swizzle(blockIdx.x, nwg);
+  const int tile_m = tile / p.n_tiles, tile_n = tile % p.n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ntaps = p.KH * p.KW;
+  const int cslices = p.Cin >> 4;
+  const int KT = ntaps * cslices;
+
+  // ---- per-lane DMA state: lane (row = l>>1, half = l&1) of piece j fills LDS row rb*32+row, 16-byte half `half`
+  const int l_row = lane >> 1, l_half = lane & 1;
+  int a_off[IA];
+  unsigned a_mask[IA];
+  int b_off[IB];
+  {
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int j = wave + NW * i;
+      a_off[i] = 0;
+      a_mask[i] = 0;
+      if (j < NA) {
+        const int rb = j / 3, plane = j - rb * 3;
+        const int row = rb * 32 + l_row;
+        const int hsrc = l_half ^ ((row >> 3) & 1);
+        const int m = m0 + row;
+        if (m < p.M) {
+          const int b = m / ohw;
+          const int rem = m - b * ohw;
+          const int oh = rem / p.OW;
+          const int ow = rem - oh * p.OW;
+          const int ih0 = oh * p.stride_h - p.pad_h, iw0 = ow * p.stride_w - p.pad_w;
+          a_off[i] = ((b * p.H + ih0) * p.W + iw0) * cslices * 96 + plane * 32 + hsrc * 16;
+          unsigned mk = 0;
+          for (int kh = 0; kh < p.KH; ++kh)
+            for (int kw = 0; kw < p.KW; ++kw)
+              if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mk |= 1u << (kh * p.KW + kw);
+          a_mask[i] = mk;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int j = wave + NW * i;
+      b_off[i] = -1;
+      if (j < NB) {
+        const int rb = j / 3, plane = j - rb * 3;
+        const int row = rb * 32 + l_row;
+        const int hsrc = l_half ^ ((row >> 3) & 1);
+        const int n = n0 + row;
+        if (n < p.N) b_off[i] = n * (p.K >> 4) * 96 + plane * 32 + hsrc * 16;
+      }
+    }
+  }
+  char* const lds_a = reinterpret_cast<char*>(As);
+  char* const lds_b = reinterpret_cast<char*>(Bs);
+  auto dma = [&](int kt, int buf) {
+    const int cs = kt / ntaps;
+    const int tap = kt - cs * ntaps;
+    const int kh = tap / p.KW;
+    const int kw = tap - kh * p.KW;
+    const int dA = ((kh * p.W + kw) * cslices + cs) * 96;
+    const int dB = (tap * cslices + cs) * 96;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int j = wave + NW * i;
+      if (j < NA) {
+        const int rb = j / 3, plane = j - rb * 3;
+        const unsigned off = ((a_mask[i] >> tap) & 1u) ? (unsigned)(a_off[i] + dA) : p.xp_zero;
+        char* dst = lds_a + ((buf * 3 + plane) * BM + rb * 32) * (ROWB * 2);
+        __builtin_amdgcn_global_load_lds((qea_glob_void*)(p.xp + off), (qea_lds_void*)dst, 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int j = wave + NW * i;
+      if (j < NB) {
+        const int rb = j / 3, plane = j - rb * 3;
+        const unsigned off = (b_off[i] >= 0) ? (unsigned)(b_off[i] + dB) : p.wp_zero;
+        char* dst = lds_b + ((buf * 3 + plane) * BN + rb * 32) * (ROWB * 2);
+        __builtin_amdgcn_global_load_lds((qea_glob_void*)(p.wp + off), (qea_lds_void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int hsw = (fh ^ ((fr >> 3) & 1)) * 8;
+  dma(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) dma(kt + 1, cur ^ 1);      // lands under the MFMAs below; __syncthreads() waits for it (vmcnt)
+    const __bf16* a_src = As + (size_t)cur * 3 * BM * ROWB + (wm * TM + fr) * ROWB + hsw;
+    const __bf16* b_src = Bs + (size_t)cur * 3 * BN * ROWB + (wn * TN + fr) * ROWB + hsw;
+    bf16x8 af[3][MI], bf[3][NJ];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(a_src + pl * BM * ROWB + i * 32 * ROWB);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(b_src + pl * BN * ROWB + j * 32 * ROWB);
+    }
+    // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of conv_igemm_bf3_kernel
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+      }
+    // hipcc otherwise hoists the barrier (and the vmcnt(0) in front of it) above the register-only MFMAs, which exposes
+    // the whole DMA latency of the next stage instead of hiding it under this stage's matrix work
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  conv_epilogue<MI, NJ, TM, TN>(p, acc, m0, n0, wm, wn, fr, fh);
+}
+
+// fp32 rows [M][ld] (C channels used, C % 16 == 0) -> P3 planes + a 128-byte zero tail.  One thread per 8 channels.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int ld, long long M, int C, __bf16* __restrict__ planes) {
+  const int c8n = C >> 3;
+  const long long total = M * c8n;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e < 8) {                                    // zero tail (128 bytes = 64 bf16) behind the planes
+    bf16x8 z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
+    *reinterpret_cast<bf16x8*>(planes + M * C * 3 + e * 8) = z;
+  }
+  if (e >= total) return;
+  const long long row = e / c8n;
+  const int c8 = (int)(e - row * c8n);
+  const float* src = x + row * ld + c8 * 8;
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+  const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
+  bf16x4 h0, m0, l0, h1, m1, l1;
+  qea_split3(v0, h0, m0, l0);
+  qea_split3(v1, h1, m1, l1);
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = h0[k]; h[k + 4] = h1[k];
+    m[k] = m0[k]; m[k + 4] = m1[k];
+    l[k] = l0[k]; l[k + 4] = l1[k];
+  }
+  __bf16* dst = planes + ((row * (C >> 4) + (c8 >> 1)) * 3) * 16 + (c8 & 1) * 8;
+  *reinterpret_cast<bf16x8*>(dst) = h;
+  *reinterpret_cast<bf16x8*>(dst + 16) = m;
+  *reinterpret_cast<bf16x8*>(dst + 32) = l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / pad 1 / stride 1 convolution on pre-split operands with the INPUT TILE RESIDENT in LDS ("P3H").
+// conv_igemm_p3_kernel re-fetches the 256 input rows of its tile for every one of the nine taps: 36.9 KB of L2 -> LDS
+// traffic per 16-deep K stage and workgroup, 24 B per clock and CU at full MFMA rate — three quarters of what a CU can
+// gather from L2 at all, and the measured ceiling of that kernel (225 TFLOP/s on the widest layer).  Here the M tile is
+// 256 output pixels forming whole image rows (a band of TH rows of one image, or G whole small images), so the nine taps
+// of a 16-channel slice read the SAME (TH+2) x (W+2) input halo at nine shifts: the halo slice (three planes) is brought
+// into LDS once per channel slice, spread over the taps of the previous slice, and only the filter stage (BN rows x 96
+// bytes) still moves per tap: 15 KB instead of 36.9 KB per stage.  One 8-wave workgroup per CU (119 KB of LDS), so the
+// loop is software-pipelined inside each wave: fragments of tap t+1 are read from LDS while the 24 MFMAs of tap t issue,
+// the filter stage of tap t+2 is in flight (3-slot ring), one barrier per tap.  K order, LDS row swizzle and MFMA sequence
+// are those of conv_igemm_bf3_kernel / conv_igemm_p3_kernel: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+struct HaloGeom {
+  int TH, G, HW_, HH, HP;   // band rows, images per tile, halo width / height, halo pixels per tile (G*HH*HW_)
+  bool ok;
+};
+
+template <int BM>
+struct P3H {
+  static constexpr int NW = BM / 32;                       // waves: BM/64 in M x 2 in N (wave tile 64x64, BN = 128)
+  static constexpr int NT = NW * 64;
+  static constexpr int HP_MAX = BM == 256 ? 448 : 264;     // halo pixels a tile may need
+  static constexpr int A_BYTES = HP_MAX * 32;              // one plane of one halo buffer
+  static constexpr int RING = 2;                           // filter stages in LDS
+  static constexpr int LDS = 2 * 3 * A_BYTES + RING * 3 * 128 * 32;   // 110 KB (one workgroup per CU) / 74 KB (two per CU)
+};
+
+template <int BM>
+inline HaloGeom p3h_geom(int H, int W) {
+  HaloGeom g{0, 0, 0, 0, 0, false};
+  if (W <= 0 || H <= 0 || BM % W) return g;
+  const int rows = BM / W;
+  if (rows >= H) {
+    if (rows % H) return g;
+    g.TH = H;
+    g.G = rows / H;
+  } else {
+    if (H % rows) return g;
+    g.TH = rows;
+    g.G = 1;
+  }
+  g.HW_ = W + 2;
+  g.HH = g.TH + 2;
+  g.HP = g.G * g.HH * g.HW_;
+  g.ok = g.HP <= P3H<BM>::HP_MAX;
+  return g;
+}
+
+// BM = 256: 8 waves, one workgroup per CU.  BM = 128: 4 waves and 74 KB of LDS, TWO independent workgroups per CU — each
+// SIMD then hosts one wave of either, and one workgroup's barrier / prologue gaps are filled by the other's matrix work.
+// XP = 1: the input comes pre-split (x_planes, LDS-DMA).  XP = 0: the input is the fp32 tensor itself — each thread gathers
+// its few float4 of the NEXT slice's halo during the first taps, splits them once and writes the three planes two taps
+// later: the split work of conv_igemm_bf3_kernel divided by nine (one halo per nine taps), no planes in HBM.
+template <int BM, int XP>
+__global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv3x3_p3h_kernel(const ConvArgs p, const HaloGeom hg) {
+  using Cfg = P3H<BM>;
+  constexpr int BN = 128, NW = Cfg::NW, NT = Cfg::NT, TM = 64, TN = 64, MI = 2, NJ = 2;
+  constexpr int A_BYTES = Cfg::A_BYTES, RING = Cfg::RING;
+  constexpr int IAW = (3 * ((Cfg::HP_MAX + 31) / 32) + NW - 1) / NW;   // halo DMA pieces per wave and channel slice (<= 7)
+  constexpr int IBW = (12 + NW - 1) / NW;                              // filter DMA pieces per wave and tap
+  static_assert(IAW <= 8, "the halo pieces of the next slice are issued one per tap, taps 0..7");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds_a = reinterpret_cast<char*>(smem);            // [2][3][HP_MAX][32 B]
+  char* const lds_b = lds_a + 2 * 3 * A_BYTES;                  // [RING][3][BN][32 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.m_tiles * p.n_tiles;
+  const int tile = qea_xcd_swizzle(blockIdx.x, nwg);
+  const int tile_m = tile / p.n_tiles, tile_n = tile % p.n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int cslices = p.Cin >> 4;
+  const int KT = 9 * cslices;
+  const int l_row = lane >> 1, l_half = lane & 1;
+  const int rows_per_img = p.H / hg.TH;                          // bands per image (G == 1) or 1
+  const int img0 = (hg.G > 1) ? tile_m * hg.G : tile_m / rows_per_img;
+  const int y0 = (hg.G > 1) ? 0 : (tile_m % rows_per_img) * hg.TH;
+
+  // ---- halo DMA state (XP == 1): piece j of a slice = plane (j % 3) of halo pixels [32*(j/3), 32*(j/3)+32)
+  const int npieces = 3 * ((hg.HP + 31) >> 5);
+  int ha_off[IAW];
+  if (XP) {
+#pragma unroll
+    for (int i = 0; i < IAW; ++i) {
+      const int j = wave + NW * i;
+      ha_off[i] = -1;
+      if (j < npieces) {
+        const int rb = j / 3, plane = j - rb * 3;
+        const int hp = rb * 32 + l_row;
+        const int hsrc = l_half ^ ((hp >> 3) & 1);
+        if (hp < hg.HP) {
+          const int g = hp / (hg.HH * hg.HW_);
+          const int rem = hp - g * hg.HH * hg.HW_;
+          const int hy = rem / hg.HW_, hx = rem - hy * hg.HW_;
+          const int b = img0 + g, iy = y0 + hy - 1, ix = hx - 1;
+          if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            ha_off[i] = ((b * p.H + iy) * p.W + ix) * cslices * 96 + plane * 32 + hsrc * 16;
+        }
+      }
+    }
+  }
+  // ---- XP == 0: fp32 gather state.  Chunk q of this thread = float4 number (tid + NT q) % 4 of halo pixel (tid + NT q) / 4
+  constexpr int NQ = (Cfg::HP_MAX * 4 + NT - 1) / NT;    // 4 (BM 256) / 5 (BM 128)
+  static_assert(NQ <= 5, "chunk q is loaded at tap q and written at tap q + 2 <= 6");
+  int gq_off[NQ];                                        // element offset of the pixel in x (ldx units), -1: zero, -2: no chunk
+  int gq_lds[NQ];                                        // byte offset in a halo plane
+  f32x4 gq_reg[NQ];
+  if (XP == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = tid + NT * q;
+      const int hp = e >> 2, kc = e & 3;
+      gq_off[q] = -2;
+      gq_lds[q] = hp * 32 + (((kc >> 1) ^ ((hp >> 3) & 1)) << 4) + (kc & 1) * 8;
+      if (hp < hg.HP) {
+        const int g = hp / (hg.HH * hg.HW_);
+        const int rem = hp - g * hg.HH * hg.HW_;
+        const int hy = rem / hg.HW_, hx = rem - hy * hg.HW_;
+        const int b = img0 + g, iy = y0 + hy - 1, ix = hx - 1;
+        gq_off[q] = -1;
+        if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) gq_off[q] = ((b * p.H + iy) * p.W + ix) * p.ldx + kc * 4;
+      }
+    }
+  }
+  // ---- filter DMA state: 12 pieces per tap (3 planes x 4 row blocks of 32 filter rows)
+  int hb_off[IBW];
+#pragma unroll
+  for (int i = 0; i < IBW; ++i) {
+    const int j = wave + NW * i;
+    hb_off[i] = -1;
+    if (j < 12) {
+      const int rb = j / 3, plane = j - rb * 3;
+      const int row = rb * 32 + l_row;
+      const int hsrc = l_half ^ ((row >> 3) & 1);
+      const int n = n0 + row;
+      if (n < p.N) hb_off[i] = n * (p.K >> 4) * 96 + plane * 32 + hsrc * 16;
+    }
+  }
+  auto gather_q = [&](int q, int cs) {                   // issue the global load of chunk q for channel slice cs
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (gq_off[q] >= 0) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)gq_off[q] + cs * 16);
+    gq_reg[q] = v;
+  };
+  auto write_q = [&](int q, int buf) {                   // split chunk q and write its three planes into halo buffer buf
+    if (gq_off[q] != -2) {
+      bf16x4 h, m, l;
+      qea_split3(gq_reg[q], h, m, l);
+      char* dst = lds_a + buf * 3 * A_BYTES + gq_lds[q];
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + A_BYTES) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * A_BYTES) = l;
+    }
+  };
+  auto dma_a = [&](int i, int cs, int buf) {            // piece i of this wave for channel slice cs into halo buffer buf
+    const int j = wave + NW * i;
+    if (j < npieces) {
+      const int rb = j / 3, plane = j - rb * 3;
+      const unsigned off = (ha_off[i] >= 0) ? (unsigned)(ha_off[i] + cs * 96) : p.xp_zero;
+      char* dst = lds_a + (buf * 3 + plane) * A_BYTES + rb * 1024;
+      __builtin_amdgcn_global_load_lds((qea_glob_void*)(p.xp + off), (qea_lds_void*)dst, 16, 0, 0);
+    }
+  };
+  auto dma_b = [&](int kt, int slot) {                  // filter stage kt = (cs, tap) into ring slot
+    const int cs = kt / 9;
+    const int tap = kt - cs * 9;
+    const int dB = (tap * cslices + cs) * 96;
+#pragma unroll
+    for (int i = 0; i < IBW; ++i) {
+      const int j = wave + NW * i;
+      if (j < 12) {
+        const int rb = j / 3, plane = j - rb * 3;
+        const unsigned off = (hb_off[i] >= 0) ? (unsigned)(hb_off[i] + dB) : p.wp_zero;
+        char* dst = lds_b + ((slot * 3 + plane) * BN + rb * 32) * 32;
+        __builtin_amdgcn_global_load_lds((qea_glob_void*)(p.wp + off), (qea_lds_void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment addressing.  A: lane (fr, fh) owns output pixels wm*64 + i*32 + fr; their halo index at tap (0,0):
+  const int fr = lane & 31, fh = lane >> 5;
+  int hp0[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * TM + i * 32 + fr;                 // tile-local output pixel, raster order over (g, y, x)
+    const int g = r / (hg.TH * p.W);
+    const int rem = r - g * hg.TH * p.W;
+    const int y = rem / p.W, x = rem - y * p.W;
+    hp0[i] = (g * hg.HH + y) * hg.HW_ + x;
+  }
+  const int b_lane = (wn * TN + fr) * 32 + ((fh ^ ((fr >> 3) & 1)) << 4);   // byte offset of this lane's row in a filter plane
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 fa[2][3][MI], fb[2][3][NJ];                     // fragment sets: [set][plane][tile]
+  auto read_frags = [&](int kt, auto set_c) {            // fragments of stage kt into set `set_c` (compile-time 0/1)
+    constexpr int S = decltype(set_c)::value;
+    const int cs = kt / 9;
+    const int tap = kt - cs * 9;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int d = kh * hg.HW_ + kw;
+    const char* abase = lds_a + (cs & 1) * 3 * A_BYTES;
+    const char* bbase = lds_b + (kt % RING) * 3 * BN * 32 + b_lane;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int hp = hp0[i] + d;
+      const char* src = abase + hp * 32 + (((fh ^ (hp >> 3)) & 1) << 4);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fa[S][pl][i] = *reinterpret_cast<const bf16x8*>(src + pl * A_BYTES);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fb[S][pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * BN * 32 + j * 32 * 32);
+  };
+  auto mfmas = [&](auto set_c) {
+    constexpr int S = decltype(set_c)::value;
+    // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of conv_igemm_bf3_kernel
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][2][i], fb[S][0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][i], fb[S][2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][1][i], fb[S][1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][1][i], fb[S][0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][i], fb[S][1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][i], fb[S][0][j], acc[i][j], 0, 0, 0);
+      }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: halo of slice 0, filter stages 0 and 1
+  if (XP) {
+#pragma unroll
+    for (int i = 0; i < IAW; ++i) dma_a(i, 0, 0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) gather_q(q, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) write_q(q, 0);
+  }
+  dma_b(0, 0);
+  if (KT > 1) dma_b(1, 1);
+  __syncthreads();                                       // (hipcc waits vmcnt(0) in front of the barrier)
+  read_frags(0, C0{});
+  __syncthreads();                                       // slot 0 is refilled by the first step: every wave must have read it
+
+  // one step: MFMAs of stage kt (fragment set S) beside the fragment reads of stage kt+1 (other set), the filter DMA of
+  // stage kt+2 (into the slot whose fragments — stage kt — were read one step ago) and a share of the NEXT slice's halo
+  auto step = [&](int kt, auto cur_c, auto nxt_c) {
+    const int cs = kt / 9;
+    const int tap = kt - cs * 9;
+    if (kt + 2 < KT) dma_b(kt + 2, (kt + 2) % RING);
+    if (XP) {
+      if (cs + 1 < cslices && tap < IAW) {
+#pragma unroll
+        for (int i = 0; i < IAW; ++i)
+          if (i == tap) dma_a(i, cs + 1, (cs + 1) & 1);
+      }
+    } else if (cs + 1 < cslices) {
+      // chunk q: global load at tap q, split + LDS write two taps later (its latency hides under two taps of matrix work);
+      // the last write lands in tap 6, the first read of the new halo happens in tap 8 (fragments of the next slice's tap 0)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (tap == q) gather_q(q, cs + 1);
+        if (tap == q + 2) write_q(q, (cs + 1) & 1);
+      }
+    }
+    // unconditional (one basic block): past the last stage the reads repeat the last one into the idle fragment set
+    read_frags(kt + 1 < KT ? kt + 1 : KT - 1, nxt_c);
+    mfmas(cur_c);
+    // pin the interleave: one fragment read of the NEXT stage behind every second MFMA of this one — issued in front of
+    // the MFMA block, hipcc waits lgkmcnt(0) for them before the first MFMA (a loop-carried wait it cannot count)
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);                   // keep the barrier (and its vmcnt(0)) BEHIND the matrix work
+    __syncthreads();
+  };
+  for (int kt = 0; kt < KT; kt += 2) {
+    step(kt, C0{}, C1{});
+    step(kt + 1, C1{}, C0{});
+  }
+  conv_epilogue<MI, NJ, TM, TN>(p, acc, m0, n0, wm, wn, fr, fh);
+}
+
+template <int BM, int XP>
+int launch_p3h(const ConvArgs& a, const HaloGeom& hg, hipStream_t s) {
+  ConvArgs p = a;
+  p.m_tiles = qea_cdiv(p.M, BM);
+  p.n_tiles = qea_cdiv(p.N, 128);
+  auto kern = conv3x3_p3h_kernel<BM, XP>;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3H<BM>::LDS);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_igemm: cannot reserve %d bytes of LDS for the halo-resident tile: %s", P3H<BM>::LDS, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
+  }
+  const long long grid = (long long)p.m_tiles * p.n_tiles;
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    qea_set_error("qea_conv_igemm: grid %lld out of range", grid);
+    return QEA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(P3H<BM>::NT), P3H<BM>::LDS, s, p, hg);
+  return QEA_OK;
+}
+
+template <int BM>
+bool p3h_eligible(const qea_conv_desc* d) {
+  return d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H && d->OW == d->W &&
+         d->Cin % 32 == 0 && p3h_geom<BM>(d->H, d->W).ok;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hybrid: activations split on the fly (conv_igemm_bf3_kernel's gather), FILTER from pre-split planes by LDS-DMA
+// (conv_igemm_p3_kernel's path).  Pre-splitting an ACTIVATION costs a 10-byte-per-element HBM pass for a tensor that one
+// launch consumes (measured at B = 2048: the passes cost the 8 ms the all-DMA kernel gains), but the filter's planes are
+// made once per optimiser step (once per run for the frozen CRNN in Phase B) and shared by every M-tile: the filter share
+// of the staging work — a third of it on the 256x128 tile, two thirds on 128x256 — leaves the VALU for free.
+// Same LDS image and MFMA sequence as the other two kernels: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(WGM * WGN == 8 ? 4 : 1)))
+void conv_igemm_bf3w_kernel(const ConvArgs p) {
+  constexpr int BK = 16;
+  constexpr int NW = WGM * WGN;
+  constexpr int NT = NW * 64;
+  constexpr int ROWB = 16;
+  constexpr int KCH = BK / 4;
+  constexpr int RPP = NT / KCH;
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MI = TM / 32, NJ = TN / 32;
+  constexpr int A_LD = BM / RPP;
+  constexpr int NB = 3 * BN / 32;
+  constexpr int IB = (NB + NW - 1) / NW;
+  static_assert(BM % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem);  // [2][3][BM][ROWB]
+  __bf16* Bs = As + 2 * 3 * BM * ROWB;           // [2][3][BN][ROWB]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nwg = p.m_tiles * p.n_tiles;
+  const int tile = qea_xcd_swizzle(blockIdx.x, nwg);
+  const int tile_m = tile / p.n_tiles, tile_n = tile % p.n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ntaps = p.KH * p.KW;
+  const int cslices = p.Cin >> 4;
+
+  IgemmGather<A_LD, 0, BK, RPP> g;               // activations only
+  g.init(p, tid, m0, n0);
+  const int lrow = g.lrow, kc = g.kc;
+  const int KT = ntaps * cslices;
+  const int l_row = lane >> 1, l_half = lane & 1;
+  int b_off[IB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int j = wave + NW * i;
+    b_off[i] = -1;
+    if (j < NB) {
+      const int rb = j / 3, plane = j - rb * 3;
+      const int row = rb * 32 + l_row;
+      const int hsrc = l_half ^ ((row >> 3) & 1);
+      const int n = n0 + row;
+      if (n < p.N) b_off[i] = n * (p.K >> 4) * 96 + plane * 32 + hsrc * 16;
+    }
+  }
+  char* const lds_b = reinterpret_cast<char*>(Bs);
+  auto dma_b = [&](int kt, int buf) {
+    const int cs = kt / ntaps;
+    const int tap = kt - cs * ntaps;
+    const int dB = (tap * cslices + cs) * 96;
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int j = wave + NW * i;
+      if (j < NB) {
+        const int rb = j / 3, plane = j - rb * 3;
+        const unsigned off = (b_off[i] >= 0) ? (unsigned)(b_off[i] + dB) : p.wp_zero;
+        char* dst = lds_b + ((buf * 3 + plane) * BN + rb * 32) * (ROWB * 2);
+        __builtin_amdgcn_global_load_lds((qea_glob_void*)(p.wp + off), (qea_lds_void*)dst, 16, 0, 0);
+      }
+    }
+  };
+  auto stage_a = [&](int buf) {
+    __bf16* a_dst = As + (size_t)buf * 3 * BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      bf16x4 h, m, l;
+      qea_split3(g.a_reg[i], h, m, l);
+      const int ro = lrow + RPP * i;
+      const int o = ro * ROWB + (((kc >> 1) ^ ((ro >> 3) & 1)) << 3) + (kc & 1) * 4;
+      *reinterpret_cast<bf16x4*>(a_dst + o) = h;
+      *reinterpret_cast<bf16x4*>(a_dst + BM * ROWB + o) = m;
+      *reinterpret_cast<bf16x4*>(a_dst + 2 * BM * ROWB + o) = l;
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int hsw = (fh ^ ((fr >> 3) & 1)) * 8;
+  dma_b(0, 0);
+  g.fetch(p, 0);
+  stage_a(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) {
+      dma_b(kt + 1, cur ^ 1);
+      g.fetch(p, kt + 1);
+    }
+    const __bf16* a_src = As + (size_t)cur * 3 * BM * ROWB + (wm * TM + fr) * ROWB + hsw;
+    const __bf16* b_src = Bs + (size_t)cur * 3 * BN * ROWB + (wn * TN + fr) * ROWB + hsw;
+    bf16x8 af[3][MI], bf[3][NJ];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(a_src + pl * BM * ROWB + i * 32 * ROWB);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(b_src + pl * BN * ROWB + j * 32 * ROWB);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+      }
+    if (kt + 1 < KT) stage_a(cur ^ 1);
+    __syncthreads();
+  }
+  conv_epilogue<MI, NJ, TM, TN>(p, acc, m0, n0, wm, wn, fr, fh);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_bf3w(const ConvArgs& a, hipStream_t s) {
+  ConvArgs p = a;
+  p.m_tiles = qea_cdiv(p.M, BM);
+  p.n_tiles = qea_cdiv(p.N, BN);
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * 16 * 2;
+  auto kern = conv_igemm_bf3w_kernel<BM, BN, WGM, WGN>;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_igemm: cannot reserve %zu bytes of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
+  }
+  const long long grid = (long long)p.m_tiles * p.n_tiles;
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    qea_set_error("qea_conv_igemm: grid %lld out of range", grid);
+    return QEA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
+  return QEA_OK;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_p3(const ConvArgs& a, hipStream_t s) {
+  ConvArgs p = a;
+  p.m_tiles = qea_cdiv(p.M, BM);
+  p.n_tiles = qea_cdiv(p.N, BN);
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * 16 * 2;
+  auto kern = conv_igemm_p3_kernel<BM, BN, WGM, WGN>;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_igemm: cannot reserve %zu bytes of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
+  }
+  const long long grid = (long long)p.m_tiles * p.n_tiles;
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    qea_set_error("qea_conv_igemm: grid %lld out of range", grid);
+    return QEA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
+  return QEA_OK;
+}
+
 template <int BM, int BN, int WGM, int WGN>
 int launch_bf3(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
@@ -379,10 +1077,10 @@ int launch_bf3(const ConvArgs& a, hipStream_t s) {
   p.n_tiles = qea_cdiv(p.N, BN);
   const size_t lds = (size_t)2 * 3 * (BM + BN) * 16 * 2;
   auto kern = conv_igemm_bf3_kernel<BM, BN, WGM, WGN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_igemm: cannot reserve %zu bytes of LDS for the %dx%d split-bf16 tile: %s", lds, BM, BN, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
   }
   const long long grid = (long long)p.m_tiles * p.n_tiles;
   if (grid <= 0 || grid > 0x7fffffffLL) {
@@ -400,10 +1098,10 @@ int launch(const ConvArgs& a, hipStream_t s) {
   p.n_tiles = qea_cdiv(p.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
   auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, BK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_igemm: cannot reserve %zu bytes of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
   }
   const long long grid = (long long)p.m_tiles * p.n_tiles;
   if (grid <= 0 || grid > 0x7fffffffLL) {
@@ -542,10 +1240,10 @@ template <int CIN, int COUT, int TH>
 int launch_halo(const ConvArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)(TH + 2) * 34 * (CIN + 4) * sizeof(float);
   auto kern = conv3x3_halo_kernel<CIN, COUT, TH>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_igemm(halo): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
   }
   const long long grid = (long long)a.B * (a.H / TH) * (a.W / 32);
   if (grid <= 0 || grid > 0x7fffffffLL) {
@@ -568,6 +1266,39 @@ int launch_halo_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   if (d->Cin == 32 && d->N == 64) return launch_halo<32, 64, 8>(a, s);
   if (d->Cin == 64 && d->N == 32) return launch_halo<64, 32, 4>(a, s);
   return launch_halo<64, 64, 4>(a, s);
+}
+
+// Tile choice for tile == 0 (measured on MI355X with tools/bench_conv.py)
+int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
+  int tile = 0;
+  // measured on MI355X (tools/bench_conv.py): the 16-deep K-slice (half the LDS, 4 workgroups per CU) wins
+  // only when the grid is large enough to keep all of them busy
+  const long long tiles128 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 128);
+  const long long tiles7 = (long long)qea_cdiv(a.M, 256) * qea_cdiv(d->N, 128);   // 256x128, 8 waves
+  const long long tiles8 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);   // 128x256, 8 waves
+  // 8-wave workgroups (twice the tile, 16-deep K-slice, 4 waves per SIMD) reach 124-135 TFLOP/s once the grid
+  // holds at least two of them per CU; below that the 4-wave tiles win (tools/bench_conv.py on MI355X)
+  // split-bf16 tiles (20-23) for every layer of 64+ output channels unless QEA_MFMA=f32 asks for the native fp32 MFMA:
+  // 160-186 TFLOP/s against 110-134, and closer to the fp64 result than the fp32 instruction (fewer accumulator roundings)
+  const long long tiles21 = (long long)qea_cdiv(a.M, 256) * qea_cdiv(d->N, 128);
+  const long long tiles22 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);
+  // (short-K launches — the transposed convs — are bound by their output traffic, and N < 128 wastes the tile)
+  const bool bf3 = qea_split_bf16_enabled() && d->N >= 128 && a.K >= 256;
+  // 33..64 output channels: the split-bf16 256x64 tile beats both the fp32 256x64 tile (132 vs 107 TFLOP/s at Cin = 128) and
+  // the fp32 LDS-halo kernel at Cin = 64 (120 vs 111); the halo kernel keeps Cin = 32 (K = 288: 102 vs 91)
+  if (qea_split_bf16_enabled() && d->N > 32 && d->N <= 64 && a.K >= 256 && d->Cin >= 64) tile = 23;
+  else if (halo_eligible(d)) tile = 4;
+  else if (d->N <= 32) tile = 3;
+  else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep; the split-bf16 256x64 tile is slower here)
+  else if (bf3 && d->N % 256 == 0 && tiles22 >= 512) tile = 22;
+  else if (bf3 && tiles21 >= 512) tile = 21;
+  else if (bf3) tile = 25;  // small grids: 8 waves on a 128x128 tile (146-166 vs 110-150 TFLOP/s for the 4-wave tile 20)
+  else if (d->N % 256 == 0 && tiles8 >= 1024) tile = 8;
+  else if (tiles7 >= 512) tile = 7;
+  else if (tiles128 >= 2048) tile = 5;
+  else if (tiles128 < 192) tile = 6;
+  else tile = 1;
+  return tile;
 }
 
 }  // namespace
@@ -599,41 +1330,25 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   a.M = d->B * d->OH * d->OW;
   a.K = d->KH * d->KW * d->Cin;
   a.m_tiles = a.n_tiles = 0;
+  a.xp = (const char*)d->x_planes;
+  a.wp = (const char*)d->w_planes;
+  a.xp_zero = a.wp_zero = 0;
 
   hipStream_t s = (hipStream_t)stream;
-  int tile = d->tile;
-  if (tile == 0) {
-    // measured on MI355X (tools/bench_conv.py): the 16-deep K-slice (half the LDS, 4 workgroups per CU) wins
-    // only when the grid is large enough to keep all of them busy
-    const long long tiles128 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 128);
-    const long long tiles7 = (long long)qea_cdiv(a.M, 256) * qea_cdiv(d->N, 128);   // 256x128, 8 waves
-    const long long tiles8 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);   // 128x256, 8 waves
-    // 8-wave workgroups (twice the tile, 16-deep K-slice, 4 waves per SIMD) reach 124-135 TFLOP/s once the grid
-    // holds at least two of them per CU; below that the 4-wave tiles win (tools/bench_conv.py on MI355X)
-    // split-bf16 tiles (20-23) for every layer of 64+ output channels unless QEA_MFMA=f32 asks for the native fp32 MFMA:
-    // 160-186 TFLOP/s against 110-134, and closer to the fp64 result than the fp32 instruction (fewer accumulator roundings)
-    const long long tiles21 = (long long)qea_cdiv(a.M, 256) * qea_cdiv(d->N, 128);
-    const long long tiles22 = (long long)qea_cdiv(a.M, 128) * qea_cdiv(d->N, 256);
-    // (short-K launches — the transposed convs — are bound by their output traffic, and N < 128 wastes the tile)
-    const bool bf3 = qea_split_bf16_enabled() && d->N >= 128 && a.K >= 256;
-    // 33..64 output channels: the split-bf16 256x64 tile beats both the fp32 256x64 tile (132 vs 107 TFLOP/s at Cin = 128) and
-    // the fp32 LDS-halo kernel at Cin = 64 (120 vs 111); the halo kernel keeps Cin = 32 (K = 288: 102 vs 91)
-    if (qea_split_bf16_enabled() && d->N > 32 && d->N <= 64 && a.K >= 256 && d->Cin >= 64) tile = 23;
-    else if (halo_eligible(d)) tile = 4;
-    else if (d->N <= 32) tile = 3;
-    else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep; the split-bf16 256x64 tile is slower here)
-    else if (bf3 && d->N % 256 == 0 && tiles22 >= 512) tile = 22;
-    else if (bf3 && tiles21 >= 512) tile = 21;
-    else if (bf3) tile = 25;  // small grids: 8 waves on a 128x128 tile (146-166 vs 110-150 TFLOP/s for the 4-wave tile 20)
-    else if (d->N % 256 == 0 && tiles8 >= 1024) tile = 8;
-    else if (tiles7 >= 512) tile = 7;
-    else if (tiles128 >= 2048) tile = 5;
-    else if (tiles128 < 192) tile = 6;
-    else tile = 1;
-  }
+  int tile = d->tile ? d->tile : pick_tile(d, a);
   if (tile == 4 && !halo_eligible(d)) {
     qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate");
     return QEA_ERR_INVALID;
+  }
+  const bool p3 = tile >= 20 && d->x_planes && d->w_planes;
+  const bool wp3 = tile >= 20 && !d->x_planes && d->w_planes;
+  if (p3 || wp3) {
+    const unsigned long long xb = p3 ? (unsigned long long)d->B * d->H * d->W * d->Cin * 6 : 0, wb = (unsigned long long)d->N * a.K * 6;
+    QEA_REQUIRE(d->Cin % 16 == 0 && xb + 128 < 0x7fffffffULL && wb + 128 < 0x7fffffffULL,
+                "qea_conv_igemm: pre-split operands need Cin %% 16 == 0 and planes below 2 GiB (%llu, %llu bytes)", xb, wb);
+    QEA_REQUIRE(((uintptr_t)d->x_planes & 15) == 0 && ((uintptr_t)d->w_planes & 15) == 0, "qea_conv_igemm: planes must be 16-byte aligned");
+    a.xp_zero = (unsigned)xb;
+    a.wp_zero = (unsigned)wb;
   }
   qea_prof_begin(QEA_PROF_CONV_IGEMM, s);
   int rc;
@@ -647,17 +1362,54 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 7: rc = launch<256, 128, 4, 2, 16>(a, s); break;  // 8 waves
     case 8: rc = launch<128, 256, 2, 4, 16>(a, s); break;  // 8 waves
     case 9: rc = launch<256, 64, 4, 1, 16>(a, s); break;   // tile 2 with half the LDS (3 workgroups per CU)
-    case 20: rc = launch_bf3<128, 128, 2, 2>(a, s); break;  // split-bf16 forms
-    case 21: rc = launch_bf3<256, 128, 4, 2>(a, s); break;
-    case 22: rc = launch_bf3<128, 256, 2, 4>(a, s); break;
-    case 23: rc = launch_bf3<256, 64, 4, 1>(a, s); break;
-    case 25: rc = launch_bf3<128, 128, 4, 2>(a, s); break;  // 8 waves on a 128x128 tile: small grids (about one workgroup per CU)
+    // split-bf16 forms; with pre-split operands (x_planes, w_planes) the LDS-DMA kernel, else the split-on-the-fly kernel
+    // (x_planes + w_planes: all-DMA kernel; w_planes only: hybrid — activations split on the fly, filter by DMA)
+    case 20: rc = p3 ? launch_p3<128, 128, 2, 2>(a, s) : wp3 ? launch_bf3w<128, 128, 2, 2>(a, s) : launch_bf3<128, 128, 2, 2>(a, s); break;
+    case 21: rc = p3 ? launch_p3<256, 128, 4, 2>(a, s) : wp3 ? launch_bf3w<256, 128, 4, 2>(a, s) : launch_bf3<256, 128, 4, 2>(a, s); break;
+    case 22: rc = p3 ? launch_p3<128, 256, 2, 4>(a, s) : wp3 ? launch_bf3w<128, 256, 2, 4>(a, s) : launch_bf3<128, 256, 2, 4>(a, s); break;
+    case 23: rc = p3 ? launch_p3<256, 64, 4, 1>(a, s) : wp3 ? launch_bf3w<256, 64, 4, 1>(a, s) : launch_bf3<256, 64, 4, 1>(a, s); break;
+    case 25: rc = p3 ? launch_p3<128, 128, 4, 2>(a, s) : wp3 ? launch_bf3w<128, 128, 4, 2>(a, s) : launch_bf3<128, 128, 4, 2>(a, s); break;  // 8 waves on a 128x128 tile: small grids
+    case 26:                                               // halo-resident 3x3: 256x128, 8 waves, one workgroup per CU
+    case 27: {                                             //                    128x128, 4 waves, two workgroups per CU
+      const bool ok = tile == 26 ? p3h_eligible<256>(d) : p3h_eligible<128>(d);
+      if (!(p3 || wp3) || !ok) {
+        qea_set_error("qea_conv_igemm: tile %d needs a pre-split filter and a 3x3 pad-1 stride-1 conv whose tiles are whole image rows", tile);
+        return QEA_ERR_INVALID;
+      }
+      if (tile == 26) rc = p3 ? launch_p3h<256, 1>(a, p3h_geom<256>(d->H, d->W), s) : launch_p3h<256, 0>(a, p3h_geom<256>(d->H, d->W), s);
+      else rc = p3 ? launch_p3h<128, 1>(a, p3h_geom<128>(d->H, d->W), s) : launch_p3h<128, 0>(a, p3h_geom<128>(d->H, d->W), s);
+      break;
+    }
     default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
   }
   if (rc != QEA_OK) return rc;
   // algorithmic bytes: input once + filter once + output once
   const double abytes = 4.0 * ((double)d->B * d->H * d->W * d->Cin + (double)d->N * a.K + (double)a.M * d->N);
   qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_conv_igemm_uses_split_bf16(const qea_conv_desc* d) {
+  if (!d || d->Cin <= 0 || d->Cin % 32 || d->B <= 0) return 0;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = d->B * d->OH * d->OW;
+  a.N = d->N;
+  a.K = d->KH * d->KW * d->Cin;
+  const int tile = d->tile ? d->tile : pick_tile(d, a);
+  return tile >= 20 ? 1 : 0;
+}
+
+extern "C" size_t qea_split_planes_bytes(int64_t M, int32_t C) { return (size_t)M * (size_t)C * 6 + 128; }
+
+extern "C" int qea_split_planes(const float* x, int32_t ld, int64_t M, int32_t C, void* planes, void* stream) {
+  QEA_REQUIRE(x && planes && M > 0 && C > 0 && C % 16 == 0 && ld >= C && ld % 4 == 0, "qea_split_planes: bad arguments (C=%d must be a multiple of 16)", C);
+  QEA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 15) == 0, "qea_split_planes: pointers must be 16-byte aligned");
+  const long long total = M * (C >> 3);
+  const long long blocks = (total + 255) / 256;
+  QEA_REQUIRE(blocks < 0x7fffffffLL, "qea_split_planes: too large");
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (long long)M, C, (__bf16*)planes);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

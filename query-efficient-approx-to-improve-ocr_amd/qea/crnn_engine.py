@@ -59,7 +59,7 @@ class CRNNEngine:
         for name, cin, cout, relu, pool in CONVS:
             a = torch.empty(B * h * w, cout, device=dev)
             ops.conv_igemm(cur, P[c + name + ".weight"], a, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1),
-                           ldx=cin, ldy=cout, bias=P[c + name + ".bias"], relu=relu)
+                           ldx=cin, ldy=cout, bias=P[c + name + ".bias"], relu=relu, w_src=("fwd", P[c + name + ".weight"]))
             acts["a" + name[-1]] = a
             dims[name] = (h, w)
             cur, ccur = a, cout
@@ -75,7 +75,7 @@ class CRNNEngine:
             M = B * h * w
             y = torch.empty(M, 512, device=dev)
             ops.conv_igemm(cur, P[c + name + ".weight"], y, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=512, KH=3, KW=3, pad=(1, 1),
-                           ldx=cin, ldy=512, bias=P[c + name + ".bias"])
+                           ldx=cin, ldy=512, bias=P[c + name + ".bias"], w_src=("fwd", P[c + name + ".weight"]))
             G = groups if bn_training else 1
             Mg = M // G
             coef = torch.empty(G, 4, 512, device=dev)
@@ -106,7 +106,7 @@ class CRNNEngine:
         # conv7 2x2 pad 0 -> [B,1,T,512], written as [T][B][512]
         seq = torch.empty(T, B, 512, device=dev)
         ops.conv_igemm(p6, P[c + "conv7.weight"], seq, B=B, H=h6, W=w6, Cin=512, OH=1, OW=T, N=512, KH=2, KW=2, ldx=512, ldy=512,
-                       bias=P[c + "conv7.bias"], out_mode=ops.OUT_TBC)
+                       bias=P[c + "conv7.bias"], out_mode=ops.OUT_TBC, w_src=("fwd", P[c + "conv7.weight"]))
         dims["conv7"] = (h6, w6)
 
         # BiLSTM x2
@@ -114,13 +114,20 @@ class CRNNEngine:
         lstm = []
         for layer in (0, 1):
             gates = torch.empty(T, B, 2 * 4 * HID, device=dev)
-            pf = torch.empty(2, 4 * HID * HID, device=dev)
-            pb = torch.empty(2, 4 * HID * HID, device=dev) if need_grad else None
+            whf, whr = P[f"lstm.weight_hh_l{layer}"], P[f"lstm.weight_hh_l{layer}_reverse"]
+
+            def pack(whf=whf, whr=whr):                       # W_hh in per-lane MFMA fragment order, both directions, fwd + bwd forms
+                pf_ = torch.empty(2, 4 * HID * HID, device=dev)
+                pb_ = torch.empty(2, 4 * HID * HID, device=dev)
+                for d_, wh in enumerate((whf, whr)):
+                    ops.lstm_pack_whh(wh, pf_[d_], pb_[d_])
+                return pf_, pb_
+            pf, pb = ops.weight_cached("whh_pack", whf, pack, also=(whr,))
             for d, suf in enumerate(("", "_reverse")):
                 bias = P[f"lstm.bias_ih_l{layer}{suf}"] + P[f"lstm.bias_hh_l{layer}{suf}"]
                 ops.conv_igemm(xin, P[f"lstm.weight_ih_l{layer}{suf}"], gates[:, :, d * 4 * HID:], B=1, H=1, W=T * B, Cin=512, OH=1,
-                               OW=T * B, N=4 * HID, KH=1, KW=1, ldx=512, ldy=2 * 4 * HID, bias=bias)
-                ops.lstm_pack_whh(P[f"lstm.weight_hh_l{layer}{suf}"], pf[d], pb[d] if need_grad else None)
+                               OW=T * B, N=4 * HID, KH=1, KW=1, ldx=512, ldy=2 * 4 * HID, bias=bias,
+                               w_src=("fwd", P[f"lstm.weight_ih_l{layer}{suf}"]))
             cst = torch.empty(T, B, 2 * HID, device=dev)
             y = torch.empty(T, B, 2 * HID, device=dev)
             ops.lstm_layer_fwd(gates, cst, y, pf, T, B)
@@ -130,7 +137,7 @@ class CRNNEngine:
         vp = self.vpad
         logits = torch.zeros(T * B, vp, device=dev)
         ops.conv_igemm(xin, P["linear.weight"], logits, B=1, H=1, W=T * B, Cin=512, OH=1, OW=T * B, N=self.vocab, KH=1, KW=1, ldx=512,
-                       ldy=vp, bias=P["linear.bias"])
+                       ldy=vp, bias=P["linear.bias"], w_src=("fwd", P["linear.weight"]))
         lp = torch.zeros(T * B, vp, device=dev)
         ops.log_softmax_fwd(logits, vp, lp, vp, T * B, self.vocab)
         out = lp.view(T, B, vp)[:, :, :self.vocab]
@@ -171,12 +178,17 @@ class CRNNEngine:
                 ops.colsum(dlogits, vp, TB, vp, dbl)
                 G["linear.bias"].add_(dbl[:V])
             side.run(linear_grads, dlogits)
-        wpad = torch.zeros(vp, 512, device=dev)
-        wpad[:V].copy_(P["linear.weight"])
-        wlT = torch.empty(512, vp, device=dev)
-        ops.transpose2d(wpad, wlT, vp, 512)
+        wlin = P["linear.weight"]
+
+        def padded_T():
+            wpad = torch.zeros(vp, 512, device=dev)
+            wpad[:V].copy_(wlin)
+            out = torch.empty(512, vp, device=dev)
+            ops.transpose2d(wpad, out, vp, 512)
+            return out
+        wlT = ops.weight_cached(("padT", vp), wlin, padded_T)
         dy = torch.empty(T, B, 512, device=dev)
-        ops.conv_igemm(dlogits, wlT, dy, B=1, H=1, W=TB, Cin=vp, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=vp, ldy=512)
+        ops.conv_igemm(dlogits, wlT, dy, B=1, H=1, W=TB, Cin=vp, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=vp, ldy=512, w_src=(("padT", vp), wlin))
 
         # BiLSTM layers, top first
         dseq_bt = None
@@ -202,18 +214,25 @@ class CRNNEngine:
                             ops.conv_wgrad(pg, qh, G[f"lstm.weight_hh_l{layer}{suf}"], B=1, PH=1, PW=n, QH=1, QW=n, R=4 * HID, Cc=HID,
                                            KH=1, KW=1, ldp=8 * HID, ldq=2 * HID, accumulate=True)
                 side.run(lstm_grads)
-            wcat = torch.cat((P[f"lstm.weight_ih_l{layer}"], P[f"lstm.weight_ih_l{layer}_reverse"]), 0)   # [2048][512]
-            wT = torch.empty(512, 8 * HID, device=dev)
-            ops.transpose2d(wcat, wT, 8 * HID, 512)
+            wf, wr = P[f"lstm.weight_ih_l{layer}"], P[f"lstm.weight_ih_l{layer}_reverse"]
+
+            def cat_T(wf=wf, wr=wr):
+                wcat = torch.cat((wf, wr), 0)                                                            # [2048][512]
+                out = torch.empty(512, 8 * HID, device=dev)
+                ops.transpose2d(wcat, out, 8 * HID, 512)
+                return out
+            wT = ops.weight_cached("catT", wf, cat_T, also=(wr,))
+            wT_planes = ops.weight_cached("catT_planes", wf, lambda wT=wT: ops.split_planes(wT, 8 * HID, 512, 8 * HID), also=(wr,))
             if layer == 1:
                 dxl = torch.empty(T, B, 512, device=dev)
-                ops.conv_igemm(gates, wT, dxl, B=1, H=1, W=TB, Cin=8 * HID, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512)
+                ops.conv_igemm(gates, wT, dxl, B=1, H=1, W=TB, Cin=8 * HID, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512,
+                               w_planes=wT_planes)
                 dy = dxl
             else:
                 # rows (t,b) -> output row b*T + t : the gradient of conv7's output in its own [B,1,T,512] order
                 dseq_bt = torch.empty(B, T, 512, device=dev)
                 ops.conv_igemm(gates, wT, dseq_bt, B=T, H=1, W=B, Cin=8 * HID, OH=1, OW=B, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512,
-                               out_mode=ops.OUT_TBC)
+                               out_mode=ops.OUT_TBC, w_planes=wT_planes)
 
         # conv7 (2x2, pad 0) backward
         h6, w6 = ctx["h6"], ctx["w6"]
@@ -224,10 +243,10 @@ class CRNNEngine:
                 ops.conv_wgrad(dseq_bt, p6, G[c + "conv7.weight"], B=B, PH=1, PW=T, QH=h6, QW=w6, R=512, Cc=512, KH=2, KW=2, ldp=512,
                                ldq=512, accumulate=True)
             side.run(conv7_grads, dseq_bt)
-        w7t = torch.empty(512, 2, 2, 512, device=dev)
-        ops.filter_flip_transpose(P[c + "conv7.weight"], w7t, 512, 512, 2, 2)
+        w7t = ops.flip_transposed(P[c + "conv7.weight"], 512, 512, 2, 2)
         dp6 = torch.empty(B * h6 * w6, 512, device=dev)
-        ops.conv_igemm(dseq_bt, w7t, dp6, B=B, H=1, W=T, Cin=512, OH=h6, OW=w6, N=512, KH=2, KW=2, pad=(1, 1), ldx=512, ldy=512)
+        ops.conv_igemm(dseq_bt, w7t, dp6, B=B, H=1, W=T, Cin=512, OH=h6, OW=w6, N=512, KH=2, KW=2, pad=(1, 1), ldx=512, ldy=512,
+                       w_src=("flipT", P[c + "conv7.weight"]))
         # pool (2,1) backward -> grad of a6 (ReLU handled by bn_bwd's mask)
         h, w = dims["conv6"]
         da = torch.empty(B * h * w, 512, device=dev)
@@ -253,10 +272,10 @@ class CRNNEngine:
                     ops.conv_wgrad(dy_, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=512, Cc=cin, KH=3, KW=3,
                                    pad=(1, 1), ldp=512, ldq=cin, accumulate=True)
                 side.run(bn_conv_grads, dy_)
-            wt = torch.empty(cin, 3, 3, 512, device=dev)
-            ops.filter_flip_transpose(P[c + name + ".weight"], wt, 512, cin, 3, 3)
+            wt = ops.flip_transposed(P[c + name + ".weight"], 512, cin, 3, 3)
             da = torch.empty(M, cin, device=dev)
-            ops.conv_igemm(dy_, wt, da, B=B, H=h, W=w, Cin=512, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=512, ldy=cin)
+            ops.conv_igemm(dy_, wt, da, B=B, H=h, W=w, Cin=512, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=512, ldy=cin,
+                           w_src=("flipT", P[c + name + ".weight"]))
         # da = grad of p4 [B,4,W/4,256]
         # conv4 (+ReLU, pool (2,1)), conv3 (+ReLU), conv2 (+ReLU, pool (2,2))
         dcur = da
@@ -276,13 +295,12 @@ class CRNNEngine:
                     ops.conv_wgrad(dyc, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
                                    pad=(1, 1), ldp=cout, ldq=cin, accumulate=True)
                 side.run(conv_grads, dyc)
-            wt = torch.empty(cin, 3, 3, cout, device=dev)
-            ops.filter_flip_transpose(P[c + name + ".weight"], wt, cout, cin, 3, 3)
+            wt = ops.flip_transposed(P[c + name + ".weight"], cout, cin, 3, 3)
             dnext = torch.empty(M, cin, device=dev)
             # conv4's input a3 is a bare ReLU output (no pool in between): fuse its mask here
             mask = acts["a3"] if name == "conv4" else None
             ops.conv_igemm(dyc, wt, dnext, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cin,
-                           mask=mask, ldmask=cin if mask is not None else 0)
+                           mask=mask, ldmask=cin if mask is not None else 0, w_src=("flipT", P[c + name + ".weight"]))
             dcur = dnext
         # dcur = grad of p1 [B,16,W/2,64]; conv1
         dy1 = torch.empty(B * H * W, 64, device=dev)

@@ -4,6 +4,7 @@ Every function takes CUDA (ROCm) fp32 tensors, passes raw device pointers + the 
 stream to libqea_hip.so and raises on any error.  No CPU implementation exists here.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -41,14 +42,91 @@ def workspace(nbytes, device):
     return buf
 
 
+def split_planes(x, ld, M, Cc):
+    """fp32 rows [M][ld] (Cc channels used) -> the P3 pre-split format (include/qea_hip.h: qea_split_planes) as a byte tensor."""
+    L = _lib.lib()
+    out = torch.empty(L.qea_split_planes_bytes(M, Cc), dtype=torch.uint8, device=x.device)
+    _lib.check(L.qea_split_planes(_ptr(x), ld, M, Cc, out.data_ptr(), _stream()), "qea_split_planes")
+    return out
+
+
+PRESPLIT = {"on": True, "x": False}     # tests / tools: "on" = pre-split filters (default), "x" = pre-split activations too
+
+# ---- derived forms of WEIGHTS (dgrad filter layouts, transposes, P3 planes), kept until the weights change.
+# A weight tensor changes either through torch (load_state_dict, copy_: its _version moves) or through the fused Adam kernel
+# (raw pointer writes: qea.optim.FusedAdam.step calls bump_weight_epoch()).  With the CRNN frozen in Phase B its derived forms
+# are built once, not once per step (round 1 re-derived 390 filter layouts per step).  Nothing is cached while a hipGraph is
+# being captured: a replay must re-derive from the weights it finds.
+_wcache = {}
+_wepoch = [0]
+WEIGHT_CACHE = {"on": True}
+
+
+def bump_weight_epoch():
+    _wepoch[0] += 1
+
+
+def weight_cached(kind, w, build, also=()):
+    """build() -> tensor(s) derived from the weight tensor `w` (and the tensors in `also`) only; cached per (kind, the
+    tensor OBJECT) until one of them changes.  Entries die with the tensor object (weakref), so a new tensor that happens
+    to reuse the address of a freed one can never hit."""
+    if not WEIGHT_CACHE["on"] or torch.cuda.is_current_stream_capturing():
+        return build()
+    key = (kind, id(w))
+    ver = (w.data_ptr(), w._version, _wepoch[0], _stream()) + tuple((id(t), t.data_ptr(), t._version) for t in also)
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is w:
+        return hit[1]
+    val = build()
+    _wcache[key] = (ver, val, weakref.ref(w, lambda _r, key=key: _wcache.pop(key, None)))
+    return val
+
+
+def flip_transposed(w, Co, Ci, KH, KW):
+    """wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]: the filter of the input-gradient convolution (cached)."""
+    def build():
+        wt = torch.empty(Ci, KH, KW, Co, device=w.device)
+        filter_flip_transpose(w, wt, Co, Ci, KH, KW)
+        return wt
+    return weight_cached(("flipT", Co, Ci, KH, KW), w, build)
+
+
+def transposed(w, R, Cc):
+    """out[c][r] = w[r][c] (cached)."""
+    def build():
+        out = torch.empty(Cc, R, device=w.device)
+        transpose2d(w, out, R, Cc)
+        return out
+    return weight_cached(("T", R, Cc), w, build)
+
+
 def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(1, 1), ldx, ldy,
                scale=None, bias=None, mask=None, ldmask=0, relu=False, accumulate=False,
-               out_mode=OUT_NHWC, tile=0):
+               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None):
+    """x_planes / w_planes: operands already in the P3 format (a caller that uses a tensor in several launches splits it
+    once); when the launch runs on a split-bf16 tile and they are not given, they are made here (one HBM pass each).
+    w_src = (kind, weight tensor): `w` is a function of that weight only (itself: kind "fwd"; its cached flip_transposed /
+    transposed form: "flipT" / "T"), so its planes are cached with it until the weight changes."""
+    L = _lib.lib()
     d = _lib.ConvDesc(x=_ptr(x), w=_ptr(w), y=_ptr(y), scale=_ptr(scale), bias=_ptr(bias), mask=_ptr(mask),
                       B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW, N=N, KH=KH, KW=KW, pad_h=pad[0], pad_w=pad[1],
                       stride_h=stride[0], stride_w=stride[1], ldx=ldx, ldy=ldy, ldmask=ldmask,
-                      relu=int(relu), accumulate=int(accumulate), out_mode=out_mode, tile=tile)
-    _lib.check(_lib.lib().qea_conv_igemm(C.byref(d), _stream()), "qea_conv_igemm")
+                      relu=int(relu), accumulate=int(accumulate), out_mode=out_mode, tile=tile, x_planes=None, w_planes=None)
+    if PRESPLIT["on"] and Cin % 16 == 0 and L.qea_conv_igemm_uses_split_bf16(C.byref(d)):
+        K = KH * KW * Cin
+        if N * K * 6 < (1 << 31) - 256:
+            # the FILTER's planes are made once per weight update and shared by every M-tile; an activation is consumed by one
+            # launch, so it is only taken pre-split when the caller has the planes anyway (PRESPLIT["x"]: tools / tests)
+            if x_planes is None and PRESPLIT.get("x") and B * H * W * Cin * 6 < (1 << 31) - 256:
+                x_planes = split_planes(x, ldx, B * H * W, Cin)
+            if w_planes is None:
+                if w_src is not None:
+                    w_planes = weight_cached(("planes", w_src[0], N, K), w_src[1], lambda: split_planes(w, K, N, K))
+                else:
+                    w_planes = split_planes(w, K, N, K)
+            d.x_planes = x_planes.data_ptr() if x_planes is not None else None
+            d.w_planes = w_planes.data_ptr()
+    _lib.check(L.qea_conv_igemm(C.byref(d), _stream()), "qea_conv_igemm")
 
 
 def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride=(1, 1), ldp, ldq,

@@ -63,13 +63,13 @@ class UNetEngine:
             ops.bn_eval_coeff(cout, P[blk.key(i, "gamma")], P[blk.key(i, "beta")], Bf[blk.key(i, "rm")], Bf[blk.key(i, "rv")], BN_EPS,
                               None, coef[0], coef[1], coef[2], coef[3])
             ops.conv_igemm(x, w, out, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=ldo,
-                           scale=coef[2], bias=coef[3], relu=True)
+                           scale=coef[2], bias=coef[3], relu=True, w_src=("fwd", w))
             return
         y = torch.empty(M, cout, device=dev)
         if cin == 1:
             ops.conv_c1_fwd(x, w, None, y, cout, B, H, W, cout, relu=False)
         else:
-            ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=cout)
+            ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=cout, w_src=("fwd", w))
         coef = torch.empty(4, cout, device=dev)  # mean, invstd, scale, shift
         stat64 = None
         gamma, beta = P[blk.key(i, "gamma")], P[blk.key(i, "beta")]
@@ -126,10 +126,9 @@ class UNetEngine:
         for l in (4, 3, 2, 1):
             cat, hh, ww, c = cats[l]
             wup = P[f"upconv{l}.weight"]                       # [2c][2][2][c] physical (IOHW channels_last)
-            wT = torch.empty(4 * c, dcin, device=dev)
-            ops.transpose2d(wup, wT, dcin, 4 * c)
+            wT = ops.transposed(wup, dcin, 4 * c)
             ops.conv_igemm(d, wT, cat, B=B, H=h, W=w, Cin=dcin, OH=h, OW=w, N=4 * c, KH=1, KW=1, ldx=dcin, ldy=2 * c,
-                           bias=P[f"upconv{l}.bias"], out_mode=ops.OUT_CONVT)
+                           bias=P[f"upconv{l}.bias"], out_mode=ops.OUT_CONVT, w_src=("T", wup))
             ups[l] = (d, dcin, h, w)
             h, w = hh, ww
             dnew = torch.empty(B * h * w, c, device=dev)
@@ -175,10 +174,10 @@ class UNetEngine:
             w2 = P[blk.key(2, "w")]
             side.run(lambda: ops.conv_wgrad(dy2, s["a1"], G[blk.key(2, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cout, KH=3, KW=3,
                                             pad=(1, 1), ldp=cout, ldq=cout, accumulate=True), dy2)
-            w2t = torch.empty(cout, 3, 3, cout, device=dev)
-            ops.filter_flip_transpose(w2, w2t, cout, cout, 3, 3)
+            w2t = ops.flip_transposed(w2, cout, cout, 3, 3)
             da1 = torch.empty(M, cout, device=dev)
-            ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout)
+            ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout,
+                           w_src=("flipT", w2))
             dy1 = torch.empty(M, cout, device=dev)       # (dy2 may still be read by its wgrad on the side stream)
             ops.bn_bwd(da1, cout, None, 0, s["y1"], cout, M, cout, P[blk.key(1, "gamma")], s["coef1"][0], s["coef1"][1],
                        training, G[blk.key(1, "gamma")], G[blk.key(1, "beta")], dy1, cout, accumulate=True, stat64=s["st1"],
@@ -188,10 +187,11 @@ class UNetEngine:
                 return None
             side.run(lambda: ops.conv_wgrad(dy1, s["xin"], G[blk.key(1, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
                                             pad=(1, 1), ldp=cout, ldq=s["ldx"], accumulate=True), dy1)
-            w1t = torch.empty(cin, 3, 3, cout, device=dev)
-            ops.filter_flip_transpose(P[blk.key(1, "w")], w1t, cout, cin, 3, 3)
+            w1 = P[blk.key(1, "w")]
+            w1t = ops.flip_transposed(w1, cout, cin, 3, 3)
             dxin = torch.empty(M, cin, device=dev)
-            ops.conv_igemm(dy1, w1t, dxin, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cin)
+            ops.conv_igemm(dy1, w1t, dxin, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cin,
+                           w_src=("flipT", w1))
             return dxin
 
         # head
@@ -214,7 +214,7 @@ class UNetEngine:
             side.run(up_grads, dcat)
             dd = torch.empty(B * h * w, dcin, device=dev)
             ops.conv_igemm(dcat, P[f"upconv{l}.weight"], dd, B=B, H=hh, W=ww, Cin=c, OH=h, OW=w, N=dcin, KH=2, KW=2, stride=(2, 2),
-                           ldx=2 * c, ldy=dcin)
+                           ldx=2 * c, ldy=dcin, w_src=("fwd", P[f"upconv{l}.weight"]))
         # bottleneck, then encoder 4..1: skip grad (dcat[:, c:]) + pool backward of the deeper level
         dpool = block_bwd(self.bott, dd, self.bott.cout)
         for l in (4, 3, 2, 1):

@@ -605,7 +605,7 @@ def full64(named_params64, prefix, out):
         out[f"{prefix}{name}|sum64"] = g64.sum().item()
 
 
-COND_SHAPES = ((2, 32, 50, 1000, 6), (4, 64, 54, 4000, 6), (4, 128, 56, 3000, 4))   # B, W, weight seed, first image seed, candidates kept
+COND_SHAPES = ((2, 32, 50, 1000, 6), (4, 64, 54, 4000, 6), (4, 128, 56, 3000, 8))   # B, W, weight seed, first image seed, candidates kept
 
 
 def make_conditioned():

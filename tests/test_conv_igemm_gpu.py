@@ -120,3 +120,84 @@ def test_split_bf16_is_not_reduced_precision():
             ops.conv_wgrad(dy.cuda(), x.cuda(), dw, B=B, PH=H, PW=W, QH=H, QW=W, R=Co, Cc=Ci, KH=3, KW=3, pad=(1, 1), ldp=Co, ldq=Ci, tile=tile)
             errs[tile] = ((dw.cpu().double().view(Co, 9, Ci) - refw).norm() / refw.norm()).item()
         assert errs[20] <= max(1.25 * errs[9], 2 * ULP), errs
+
+
+@pytest.mark.parametrize("tile", [20, 21, 22, 23, 25])
+@pytest.mark.parametrize("shape", [(5, 7, 9, 64, 40, 3, 1), (3, 8, 32, 128, 256, 3, 1), (2, 4, 32, 512, 512, 3, 1), (4, 2, 32, 512, 512, 2, 0),
+                                   (1, 1, 300, 512, 95, 1, 0), (2, 8, 16, 64, 128, 2, 0)])
+def test_presplit_planes_bit_identical(tile, shape):
+    """conv_igemm_p3_kernel (operands pre-split into bf16 planes once, staged by LDS-DMA) runs the very MFMA sequence of
+    conv_igemm_bf3_kernel (operands split on the fly) on the very same bf16 values: the outputs must agree BIT FOR BIT on
+    every tile, ragged M / N, zero padding, 2x2 stride-2 and 1x1 GEMM shapes included."""
+    from qea import ops
+    B, H, W, Cin, Cout, k, pad = shape
+    stride = 2 if (k == 2 and pad == 0 and H == 8) else 1
+    g = torch.Generator().manual_seed(tile * 100 + Cin)
+    x = (torch.randn(B, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(B, H, W, Cin, generator=g))).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) * 0.05).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    outs = []
+    for pre, prex in ((False, False), (True, False), (True, True)):       # split on the fly / filter planes (hybrid) / both operands
+        ops.PRESPLIT["on"], ops.PRESPLIT["x"] = pre, prex
+        try:
+            y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+            ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW, N=Cout, KH=k, KW=k, pad=(pad, pad), stride=(stride, stride),
+                           ldx=Cin, ldy=Cout, bias=bias, relu=True, tile=tile)
+            outs.append(y)
+        finally:
+            ops.PRESPLIT["on"], ops.PRESPLIT["x"] = True, False
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[2]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_presplit_from_a_strided_concat_slice():
+    """x is the right half of a wider (UNet concat) buffer: the split pass reads with the pixel stride, the planes are compact."""
+    from qea import ops
+    B, H, W, Cin, Cout = 3, 8, 32, 128, 128
+    g = torch.Generator().manual_seed(5)
+    cat = torch.randn(B, H, W, 2 * Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).cuda()
+    x = cat[..., Cin:]
+    outs = []
+    for pre in (False, True):
+        ops.PRESPLIT["on"], ops.PRESPLIT["x"] = pre, pre
+        try:
+            y = torch.empty(B, H, W, Cout, device="cuda")
+            ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad=(1, 1), ldx=2 * Cin, ldy=Cout, tile=21)
+            outs.append(y)
+        finally:
+            ops.PRESPLIT["on"], ops.PRESPLIT["x"] = True, False
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), padding=1).permute(0, 2, 3, 1)
+    assert (outs[1].cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 32, 128, 256), (2, 4, 32, 512, 512), (3, 4, 16, 256, 256), (2, 16, 64, 64, 128), (5, 4, 16, 128, 130),
+                                   (9, 4, 32, 256, 512), (1, 8, 32, 64, 64)])
+def test_halo_resident_tile_bit_identical(shape):
+    """tile 26 = conv3x3_p3h_kernel (input halo of a 16-channel slice resident in LDS for its nine taps, software-pipelined
+    fragment reads, 3-slot filter ring) against the split-on-the-fly kernel on tile 21: same K order, same MFMA sequence ->
+    the same bits.  Whole images per tile (8x32), several images per tile with a ragged last tile (4x16 with B = 3, 5),
+    bands of image rows (16x64), ragged N."""
+    from qea import ops
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(H * 1000 + Cin)
+    x = (torch.randn(B, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(B, H, W, Cin, generator=g))).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    outs = []
+    for tile, pre, prex in ((21, False, False), (26, True, True), (26, True, False)):   # XP = 1 (planes by DMA) and XP = 0 (fp32 gather)
+        ops.PRESPLIT["on"], ops.PRESPLIT["x"] = pre, prex
+        try:
+            y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+            ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad=(1, 1), ldx=Cin, ldy=Cout, bias=bias, tile=tile)
+            outs.append(y)
+        finally:
+            ops.PRESPLIT["on"], ops.PRESPLIT["x"] = True, False
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[2]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    assert (outs[1].cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
