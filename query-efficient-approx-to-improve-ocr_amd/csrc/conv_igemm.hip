@@ -13,7 +13,6 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
-#include <type_traits>
 
 namespace {
 
@@ -572,330 +571,6 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3x3 / pad 1 / stride 1 convolution on pre-split operands with the INPUT TILE RESIDENT in LDS ("P3H").
-// conv_igemm_p3_kernel re-fetches the 256 input rows of its tile for every one of the nine taps: 36.9 KB of L2 -> LDS
-// traffic per 16-deep K stage and workgroup, 24 B per clock and CU at full MFMA rate — three quarters of what a CU can
-// gather from L2 at all, and the measured ceiling of that kernel (225 TFLOP/s on the widest layer).  Here the M tile is
-// 256 output pixels forming whole image rows (a band of TH rows of one image, or G whole small images), so the nine taps
-// of a 16-channel slice read the SAME (TH+2) x (W+2) input halo at nine shifts: the halo slice (three planes) is brought
-// into LDS once per channel slice, spread over the taps of the previous slice, and only the filter stage (BN rows x 96
-// bytes) still moves per tap: 15 KB instead of 36.9 KB per stage.  One 8-wave workgroup per CU (119 KB of LDS), so the
-// loop is software-pipelined inside each wave: fragments of tap t+1 are read from LDS while the 24 MFMAs of tap t issue,
-// the filter stage of tap t+2 is in flight (3-slot ring), one barrier per tap.  K order, LDS row swizzle and MFMA sequence
-// are those of conv_igemm_bf3_kernel / conv_igemm_p3_kernel: bit-identical results.
-// ---------------------------------------------------------------------------------------------
-struct HaloGeom {
-  int TH, G, HW_, HH, HP;   // band rows, images per tile, halo width / height, halo pixels per tile (G*HH*HW_)
-  bool ok;
-};
-
-template <int BM>
-struct P3H {
-  static constexpr int NW = BM / 32;                       // waves: BM/64 in M x 2 in N (wave tile 64x64, BN = 128)
-  static constexpr int NT = NW * 64;
-  static constexpr int HP_MAX = BM == 256 ? 448 : 264;     // halo pixels a tile may need
-  static constexpr int A_BYTES = HP_MAX * 32;              // one plane of one halo buffer
-  static constexpr int RING = 2;                           // filter stages in LDS
-  static constexpr int LDS = 2 * 3 * A_BYTES + RING * 3 * 128 * 32;   // 110 KB (one workgroup per CU) / 74 KB (two per CU)
-};
-
-template <int BM>
-inline HaloGeom p3h_geom(int H, int W) {
-  HaloGeom g{0, 0, 0, 0, 0, false};
-  if (W <= 0 || H <= 0 || BM % W) return g;
-  const int rows = BM / W;
-  if (rows >= H) {
-    if (rows % H) return g;
-    g.TH = H;
-    g.G = rows / H;
-  } else {
-    if (H % rows) return g;
-    g.TH = rows;
-    g.G = 1;
-  }
-  g.HW_ = W + 2;
-  g.HH = g.TH + 2;
-  g.HP = g.G * g.HH * g.HW_;
-  g.ok = g.HP <= P3H<BM>::HP_MAX;
-  return g;
-}
-
-// BM = 256: 8 waves, one workgroup per CU.  BM = 128: 4 waves and 74 KB of LDS, TWO independent workgroups per CU — each
-// SIMD then hosts one wave of either, and one workgroup's barrier / prologue gaps are filled by the other's matrix work.
-// XP = 1: the input comes pre-split (x_planes, LDS-DMA).  XP = 0: the input is the fp32 tensor itself — each thread gathers
-// its few float4 of the NEXT slice's halo during the first taps, splits them once and writes the three planes two taps
-// later: the split work of conv_igemm_bf3_kernel divided by nine (one halo per nine taps), no planes in HBM.
-template <int BM, int XP>
-__global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv3x3_p3h_kernel(const ConvArgs p, const HaloGeom hg) {
-  using Cfg = P3H<BM>;
-  constexpr int BN = 128, NW = Cfg::NW, NT = Cfg::NT, TM = 64, TN = 64, MI = 2, NJ = 2;
-  constexpr int A_BYTES = Cfg::A_BYTES, RING = Cfg::RING;
-  constexpr int IAW = (3 * ((Cfg::HP_MAX + 31) / 32) + NW - 1) / NW;   // halo DMA pieces per wave and channel slice (<= 7)
-  constexpr int IBW = (12 + NW - 1) / NW;                              // filter DMA pieces per wave and tap
-  static_assert(IAW <= 8, "the halo pieces of the next slice are issued one per tap, taps 0..7");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  char* const lds_a = reinterpret_cast<char*>(smem);            // [2][3][HP_MAX][32 B]
-  char* const lds_b = lds_a + 2 * 3 * A_BYTES;                  // [RING][3][BN][32 B]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = p.m_tiles * p.n_tiles;
-  const int tile = qea_xcd_swizzle(blockIdx.x, nwg);
-  const int tile_m = tile / p.n_tiles, tile_n = tile % p.n_tiles;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int cslices = p.Cin >> 4;
-  const int KT = 9 * cslices;
-  const int l_row = lane >> 1, l_half = lane & 1;
-  const int rows_per_img = p.H / hg.TH;                          // bands per image (G == 1) or 1
-  const int img0 = (hg.G > 1) ? tile_m * hg.G : tile_m / rows_per_img;
-  const int y0 = (hg.G > 1) ? 0 : (tile_m % rows_per_img) * hg.TH;
-
-  // ---- halo DMA state (XP == 1): piece j of a slice = plane (j % 3) of halo pixels [32*(j/3), 32*(j/3)+32)
-  const int npieces = 3 * ((hg.HP + 31) >> 5);
-  int ha_off[IAW];
-  if (XP) {
-#pragma unroll
-    for (int i = 0; i < IAW; ++i) {
-      const int j = wave + NW * i;
-      ha_off[i] = -1;
-      if (j < npieces) {
-        const int rb = j / 3, plane = j - rb * 3;
-        const int hp = rb * 32 + l_row;
-        const int hsrc = l_half ^ ((hp >> 3) & 1);
-        if (hp < hg.HP) {
-          const int g = hp / (hg.HH * hg.HW_);
-          const int rem = hp - g * hg.HH * hg.HW_;
-          const int hy = rem / hg.HW_, hx = rem - hy * hg.HW_;
-          const int b = img0 + g, iy = y0 + hy - 1, ix = hx - 1;
-          if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            ha_off[i] = ((b * p.H + iy) * p.W + ix) * cslices * 96 + plane * 32 + hsrc * 16;
-        }
-      }
-    }
-  }
-  // ---- XP == 0: fp32 gather state.  Chunk q of this thread = float4 number (tid + NT q) % 4 of halo pixel (tid + NT q) / 4
-  constexpr int NQ = (Cfg::HP_MAX * 4 + NT - 1) / NT;    // 4 (BM 256) / 5 (BM 128)
-  static_assert(NQ <= 5, "chunk q is loaded at tap q and written at tap q + 2 <= 6");
-  int gq_off[NQ];                                        // element offset of the pixel in x (ldx units), -1: zero, -2: no chunk
-  int gq_lds[NQ];                                        // byte offset in a halo plane
-  f32x4 gq_reg[NQ];
-  if (XP == 0) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int e = tid + NT * q;
-      const int hp = e >> 2, kc = e & 3;
-      gq_off[q] = -2;
-      gq_lds[q] = hp * 32 + (((kc >> 1) ^ ((hp >> 3) & 1)) << 4) + (kc & 1) * 8;
-      if (hp < hg.HP) {
-        const int g = hp / (hg.HH * hg.HW_);
-        const int rem = hp - g * hg.HH * hg.HW_;
-        const int hy = rem / hg.HW_, hx = rem - hy * hg.HW_;
-        const int b = img0 + g, iy = y0 + hy - 1, ix = hx - 1;
-        gq_off[q] = -1;
-        if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) gq_off[q] = ((b * p.H + iy) * p.W + ix) * p.ldx + kc * 4;
-      }
-    }
-  }
-  // ---- filter DMA state: 12 pieces per tap (3 planes x 4 row blocks of 32 filter rows)
-  int hb_off[IBW];
-#pragma unroll
-  for (int i = 0; i < IBW; ++i) {
-    const int j = wave + NW * i;
-    hb_off[i] = -1;
-    if (j < 12) {
-      const int rb = j / 3, plane = j - rb * 3;
-      const int row = rb * 32 + l_row;
-      const int hsrc = l_half ^ ((row >> 3) & 1);
-      const int n = n0 + row;
-      if (n < p.N) hb_off[i] = n * (p.K >> 4) * 96 + plane * 32 + hsrc * 16;
-    }
-  }
-  auto gather_q = [&](int q, int cs) {                   // issue the global load of chunk q for channel slice cs
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (gq_off[q] >= 0) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)gq_off[q] + cs * 16);
-    gq_reg[q] = v;
-  };
-  auto write_q = [&](int q, int buf) {                   // split chunk q and write its three planes into halo buffer buf
-    if (gq_off[q] != -2) {
-      bf16x4 h, m, l;
-      qea_split3(gq_reg[q], h, m, l);
-      char* dst = lds_a + buf * 3 * A_BYTES + gq_lds[q];
-      *reinterpret_cast<bf16x4*>(dst) = h;
-      *reinterpret_cast<bf16x4*>(dst + A_BYTES) = m;
-      *reinterpret_cast<bf16x4*>(dst + 2 * A_BYTES) = l;
-    }
-  };
-  auto dma_a = [&](int i, int cs, int buf) {            // piece i of this wave for channel slice cs into halo buffer buf
-    const int j = wave + NW * i;
-    if (j < npieces) {
-      const int rb = j / 3, plane = j - rb * 3;
-      const unsigned off = (ha_off[i] >= 0) ? (unsigned)(ha_off[i] + cs * 96) : p.xp_zero;
-      char* dst = lds_a + (buf * 3 + plane) * A_BYTES + rb * 1024;
-      __builtin_amdgcn_global_load_lds((qea_glob_void*)(p.xp + off), (qea_lds_void*)dst, 16, 0, 0);
-    }
-  };
-  auto dma_b = [&](int kt, int slot) {                  // filter stage kt = (cs, tap) into ring slot
-    const int cs = kt / 9;
-    const int tap = kt - cs * 9;
-    const int dB = (tap * cslices + cs) * 96;
-#pragma unroll
-    for (int i = 0; i < IBW; ++i) {
-      const int j = wave + NW * i;
-      if (j < 12) {
-        const int rb = j / 3, plane = j - rb * 3;
-        const unsigned off = (hb_off[i] >= 0) ? (unsigned)(hb_off[i] + dB) : p.wp_zero;
-        char* dst = lds_b + ((slot * 3 + plane) * BN + rb * 32) * 32;
-        __builtin_amdgcn_global_load_lds((qea_glob_void*)(p.wp + off), (qea_lds_void*)dst, 16, 0, 0);
-      }
-    }
-  };
-
-  // ---- fragment addressing.  A: lane (fr, fh) owns output pixels wm*64 + i*32 + fr; their halo index at tap (0,0):
-  const int fr = lane & 31, fh = lane >> 5;
-  int hp0[MI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int r = wm * TM + i * 32 + fr;                 // tile-local output pixel, raster order over (g, y, x)
-    const int g = r / (hg.TH * p.W);
-    const int rem = r - g * hg.TH * p.W;
-    const int y = rem / p.W, x = rem - y * p.W;
-    hp0[i] = (g * hg.HH + y) * hg.HW_ + x;
-  }
-  const int b_lane = (wn * TN + fr) * 32 + ((fh ^ ((fr >> 3) & 1)) << 4);   // byte offset of this lane's row in a filter plane
-
-  f32x16 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  bf16x8 fa[2][3][MI], fb[2][3][NJ];                     // fragment sets: [set][plane][tile]
-  auto read_frags = [&](int kt, auto set_c) {            // fragments of stage kt into set `set_c` (compile-time 0/1)
-    constexpr int S = decltype(set_c)::value;
-    const int cs = kt / 9;
-    const int tap = kt - cs * 9;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const int d = kh * hg.HW_ + kw;
-    const char* abase = lds_a + (cs & 1) * 3 * A_BYTES;
-    const char* bbase = lds_b + (kt % RING) * 3 * BN * 32 + b_lane;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int hp = hp0[i] + d;
-      const char* src = abase + hp * 32 + (((fh ^ (hp >> 3)) & 1) << 4);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa[S][pl][i] = *reinterpret_cast<const bf16x8*>(src + pl * A_BYTES);
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fb[S][pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * BN * 32 + j * 32 * 32);
-  };
-  auto mfmas = [&](auto set_c) {
-    constexpr int S = decltype(set_c)::value;
-    // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of conv_igemm_bf3_kernel
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][2][i], fb[S][0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][i], fb[S][2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][1][i], fb[S][1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][1][i], fb[S][0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][i], fb[S][1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][0][i], fb[S][0][j], acc[i][j], 0, 0, 0);
-      }
-  };
-  using C0 = std::integral_constant<int, 0>;
-  using C1 = std::integral_constant<int, 1>;
-
-  // ---- prologue: halo of slice 0, filter stages 0 and 1
-  if (XP) {
-#pragma unroll
-    for (int i = 0; i < IAW; ++i) dma_a(i, 0, 0);
-  } else {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) gather_q(q, 0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) write_q(q, 0);
-  }
-  dma_b(0, 0);
-  if (KT > 1) dma_b(1, 1);
-  __syncthreads();                                       // (hipcc waits vmcnt(0) in front of the barrier)
-  read_frags(0, C0{});
-  __syncthreads();                                       // slot 0 is refilled by the first step: every wave must have read it
-
-  // one step: MFMAs of stage kt (fragment set S) beside the fragment reads of stage kt+1 (other set), the filter DMA of
-  // stage kt+2 (into the slot whose fragments — stage kt — were read one step ago) and a share of the NEXT slice's halo
-  auto step = [&](int kt, auto cur_c, auto nxt_c) {
-    const int cs = kt / 9;
-    const int tap = kt - cs * 9;
-    if (kt + 2 < KT) dma_b(kt + 2, (kt + 2) % RING);
-    if (XP) {
-      if (cs + 1 < cslices && tap < IAW) {
-#pragma unroll
-        for (int i = 0; i < IAW; ++i)
-          if (i == tap) dma_a(i, cs + 1, (cs + 1) & 1);
-      }
-    } else if (cs + 1 < cslices) {
-      // chunk q: global load at tap q, split + LDS write two taps later (its latency hides under two taps of matrix work);
-      // the last write lands in tap 6, the first read of the new halo happens in tap 8 (fragments of the next slice's tap 0)
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        if (tap == q) gather_q(q, cs + 1);
-        if (tap == q + 2) write_q(q, (cs + 1) & 1);
-      }
-    }
-    // unconditional (one basic block): past the last stage the reads repeat the last one into the idle fragment set
-    read_frags(kt + 1 < KT ? kt + 1 : KT - 1, nxt_c);
-    mfmas(cur_c);
-    // pin the interleave: one fragment read of the NEXT stage behind every second MFMA of this one — issued in front of
-    // the MFMA block, hipcc waits lgkmcnt(0) for them before the first MFMA (a loop-carried wait it cannot count)
-#pragma unroll
-    for (int q = 0; q < 12; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);                   // keep the barrier (and its vmcnt(0)) BEHIND the matrix work
-    __syncthreads();
-  };
-  for (int kt = 0; kt < KT; kt += 2) {
-    step(kt, C0{}, C1{});
-    step(kt + 1, C1{}, C0{});
-  }
-  conv_epilogue<MI, NJ, TM, TN>(p, acc, m0, n0, wm, wn, fr, fh);
-}
-
-template <int BM, int XP>
-int launch_p3h(const ConvArgs& a, const HaloGeom& hg, hipStream_t s) {
-  ConvArgs p = a;
-  p.m_tiles = qea_cdiv(p.M, BM);
-  p.n_tiles = qea_cdiv(p.N, 128);
-  auto kern = conv3x3_p3h_kernel<BM, XP>;
-  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3H<BM>::LDS);
-  if (attr_rc != (int)hipSuccess) {
-    qea_set_error("qea_conv_igemm: cannot reserve %d bytes of LDS for the halo-resident tile: %s", P3H<BM>::LDS, hipGetErrorString((hipError_t)attr_rc));
-    return QEA_ERR_LAUNCH;
-  }
-  const long long grid = (long long)p.m_tiles * p.n_tiles;
-  if (grid <= 0 || grid > 0x7fffffffLL) {
-    qea_set_error("qea_conv_igemm: grid %lld out of range", grid);
-    return QEA_ERR_INVALID;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(P3H<BM>::NT), P3H<BM>::LDS, s, p, hg);
-  return QEA_OK;
-}
-
-template <int BM>
-bool p3h_eligible(const qea_conv_desc* d) {
-  return d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H && d->OW == d->W &&
-         d->Cin % 32 == 0 && p3h_geom<BM>(d->H, d->W).ok;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Hybrid: activations split on the fly (conv_igemm_bf3_kernel's gather), FILTER from pre-split planes by LDS-DMA
 // (conv_igemm_p3_kernel's path).  Pre-splitting an ACTIVATION costs a 10-byte-per-element HBM pass for a tensor that one
 // launch consumes (measured at B = 2048: the passes cost the 8 ms the all-DMA kernel gains), but the filter's planes are
@@ -1369,17 +1044,6 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 22: rc = p3 ? launch_p3<128, 256, 2, 4>(a, s) : wp3 ? launch_bf3w<128, 256, 2, 4>(a, s) : launch_bf3<128, 256, 2, 4>(a, s); break;
     case 23: rc = p3 ? launch_p3<256, 64, 4, 1>(a, s) : wp3 ? launch_bf3w<256, 64, 4, 1>(a, s) : launch_bf3<256, 64, 4, 1>(a, s); break;
     case 25: rc = p3 ? launch_p3<128, 128, 4, 2>(a, s) : wp3 ? launch_bf3w<128, 128, 4, 2>(a, s) : launch_bf3<128, 128, 4, 2>(a, s); break;  // 8 waves on a 128x128 tile: small grids
-    case 26:                                               // halo-resident 3x3: 256x128, 8 waves, one workgroup per CU
-    case 27: {                                             //                    128x128, 4 waves, two workgroups per CU
-      const bool ok = tile == 26 ? p3h_eligible<256>(d) : p3h_eligible<128>(d);
-      if (!(p3 || wp3) || !ok) {
-        qea_set_error("qea_conv_igemm: tile %d needs a pre-split filter and a 3x3 pad-1 stride-1 conv whose tiles are whole image rows", tile);
-        return QEA_ERR_INVALID;
-      }
-      if (tile == 26) rc = p3 ? launch_p3h<256, 1>(a, p3h_geom<256>(d->H, d->W), s) : launch_p3h<256, 0>(a, p3h_geom<256>(d->H, d->W), s);
-      else rc = p3 ? launch_p3h<128, 1>(a, p3h_geom<128>(d->H, d->W), s) : launch_p3h<128, 0>(a, p3h_geom<128>(d->H, d->W), s);
-      break;
-    }
     default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
   }
   if (rc != QEA_OK) return rc;
