@@ -283,10 +283,13 @@ def test_area_trainer_one_minibatch_vs_reference(tmp_path, monkeypatch):
             if k in ZERO_GRAD and tag == "crnn|":
                 continue
             ref = torch.from_numpy(fx["upd|" + tag + k + "|s"]).double()
-            e = (d[H.sample_index(d.numel())] - ref).norm().item() / max(ref.norm().item(), 1e-300)
-            worst[tag + k] = e
-            # an element whose gradient is within rounding of zero may step the other way (2*lr); everything else follows g
-            assert e <= 5e-2, (tag, k, e)
+            got = d[H.sample_index(d.numel())]
+            # Adam's first step is lr * g / (|g| + eps), i.e. +-lr for every element whose gradient is not rounding noise: an element
+            # whose gradient sits within rounding of zero may step the other way (a 2*lr difference), everything else follows g.
+            # Stated per element: at most 2 % of the sampled elements (and never fewer than 3 allowed) differ by more than lr / 5.
+            off = ((got - ref).abs() > 0.2 * lr[tag]).sum().item()
+            worst[tag + k] = off / got.numel()
+            assert off <= max(3, 0.02 * got.numel()), (tag, k, off, got.numel())
             assert abs(d.norm().item() - float(fx["upd|" + tag + k + "|l2"])) <= 2e-2 * float(fx["upd|" + tag + k + "|l2"]), (tag, k)
     # ---- CER bookkeeping after Phase B's decode (train_nn_area.py:290-304)
     dec = [str(s) for s in fx["B|decoded"]]
@@ -294,7 +297,7 @@ def test_area_trainer_one_minibatch_vs_reference(tmp_path, monkeypatch):
     for n, lab, d in zip(names, labels, dec):
         assert abs(t.sampler.cers[n] - po.levenshtein(d, lab) / max(1, len(lab))) < 1e-9, (n, lab, d, t.sampler.cers[n])
     med = sorted(worst.values())[len(worst) // 2]
-    print(f"\n[step] TrainNNPrep one minibatch vs reference: update l2 error median {med:.2e}, max {max(worst.values()):.2e}")
+    print(f"\n[step] TrainNNPrep one minibatch vs reference: share of update elements off by > lr/5: median {med:.2e}, max {max(worst.values()):.2e}")
 
 
 def test_reference_style_crnn_pickle_trains(tmp_path):
