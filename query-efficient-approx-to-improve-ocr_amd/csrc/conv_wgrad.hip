@@ -763,13 +763,223 @@ void launch_halo(const qea_wgrad_desc* d, const HaloPlan& h, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(h.grid), dim3(256), lds, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->ldp, d->ldq, h.n_tiles);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 weight gradient of the WIDE 3x3 layers (R, C multiples of 64; tile 23) with all nine taps per workgroup.
+// wgrad_bf3_kernel treats every tap as its own GEMM: each pixel of dY and X is gathered, split (5.5 VALU operations per
+// element) and staged NINE times per channel-tile pair — the PMC pass showed 2.6x the algorithmic traffic and the matrix
+// pipe 45 % busy.  Here a workgroup owns a 64 x 64 (dY-channel, X-channel) block for ALL nine taps (each wave a 32 x 32
+// sub-block: nine accumulator tiles) and walks 64-pixel tiles (TH rows x SW columns, SW = 16 or 32): the dY tile and the
+// (TH+2) x (SW+2) X halo are gathered, split and written to LDS ONCE per tile (the next tile's loads fly under this
+// tile's 216 MFMAs per wave) and the nine taps read their X fragments from the halo at nine shifts through
+// ds_read_b64_tr_b16.  Per staged element the matrix work is 9 x what the per-tap kernel gets.  Each workgroup writes its
+// block into the partial slab of its pixel split; the order-fixed splitk_reduce pass sums the slabs: bit-reproducible.
+// LDS rows = pixels x 64 channels (128 B), the two 64-byte chunks of pixel p stored at chunk ^ ((p >> 1) & 1): the four
+// pixel rows of a transposing read then fall on four different 64-byte bank ranges.
+// ---------------------------------------------------------------------------------------------
+struct Halo9Plan {
+  bool ok;
+  int sw, th, tiles_x, tiles_y, n_tiles, r_blks, c_blks, splits;
+};
+
+constexpr int H9_HP_MAX = 136;   // halo pixels: (2+2) x (32+2) or (4+2) x (16+2) = 108
+
+template <int SW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ ws, int B, int H, int W, int R, int C,
+                            int ldp, int ldq, Halo9Plan hp) {
+  constexpr int TH = 64 / SW, HW_ = SW + 2, HH = TH + 2, HP = HH * HW_;
+  constexpr int ROW = 64;                                  // bf16 per LDS pixel row
+  constexpr int P_PLANE = 64 * ROW, Q_PLANE = H9_HP_MAX * ROW;   // elements
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* Ps = reinterpret_cast<__bf16*>(smem);            // [3][64 px][64 ch]
+  __bf16* Qs = Ps + 3 * P_PLANE;                            // [3][HP_MAX px][64 ch]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int bid = blockIdx.x;
+  const int c_blk = bid % hp.c_blks;
+  bid /= hp.c_blks;
+  const int r_blk = bid % hp.r_blks;
+  const int split = bid / hp.r_blks;
+  const int r0 = r_blk * 64, c0 = c_blk * 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // gather: element e = tid + 256 i -> pixel e / 16, float4 chunk e % 16 (16 chunks = 64 channels)
+  constexpr int NP = 64 * 16 / 256;                         // 4
+  constexpr int NQ = (HP * 16 + 255) / 256;                 // 9 (SW 32) / 7 (SW 16)
+  f32x4 preg[NP], qreg[NQ];
+  auto fetch = [&](int tile) {
+    const int tx = tile % hp.tiles_x;
+    const int ty = (tile / hp.tiles_x) % hp.tiles_y;
+    const int b = tile / (hp.tiles_x * hp.tiles_y);
+    const int x0 = tx * SW, y0 = ty * TH;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int e = tid + 256 * i;
+      const int c4 = e & 15, pix = e >> 4;
+      const int py = pix / SW, px = pix - py * SW;
+      preg[i] = *reinterpret_cast<const f32x4*>(p + ((size_t)(b * H + y0 + py) * W + x0 + px) * ldp + r0 + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + 256 * i;
+      const int c4 = e & 15, hq = e >> 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (hq < HP) {
+        const int hy = hq / HW_, hx = hq - hy * HW_;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(q + ((size_t)(b * H + iy) * W + ix) * ldq + c0 + c4 * 4);
+      }
+      qreg[i] = v;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int e = tid + 256 * i;
+      const int c4 = e & 15, pix = e >> 4;
+      bf16x4 h, m, l;
+      qea_split3(preg[i], h, m, l);
+      const int o = pix * ROW + ((((c4 >> 3) ^ (pix >> 1)) & 1) << 5) + (c4 & 7) * 4;
+      *reinterpret_cast<bf16x4*>(Ps + o) = h;
+      *reinterpret_cast<bf16x4*>(Ps + P_PLANE + o) = m;
+      *reinterpret_cast<bf16x4*>(Ps + 2 * P_PLANE + o) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + 256 * i;
+      const int c4 = e & 15, hq = e >> 4;
+      if (hq < HP) {
+        bf16x4 h, m, l;
+        qea_split3(qreg[i], h, m, l);
+        const int o = hq * ROW + ((((c4 >> 3) ^ (hq >> 1)) & 1) << 5) + (c4 & 7) * 4;
+        *reinterpret_cast<bf16x4*>(Qs + o) = h;
+        *reinterpret_cast<bf16x4*>(Qs + Q_PLANE + o) = m;
+        *reinterpret_cast<bf16x4*>(Qs + 2 * Q_PLANE + o) = l;
+      }
+    }
+  };
+  // transposing-read geometry of this lane (see tr_frag): pixel (g16 >> 1) * 8 + tq (+ 4 for the second read) of the
+  // 16-pixel k-step, channels (g16 & 1) * 16 + tpp * 4 of the wave's 32-channel chunk
+  const int g16 = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
+  const int l_pix = (g16 >> 1) * 8 + tq;
+  const int l_ch = (g16 & 1) * 16 + tpp * 4;
+  auto frag = [&](const __bf16* plane, int pix, int chunk) {   // pix = LDS pixel row of this lane's first 4-pixel block
+    return tr_frag(plane + pix * ROW + (((chunk ^ (pix >> 1)) & 1) << 5) + l_ch, ROW);   // (pix + 4) >> 1 has the same parity
+  };
+
+  int tile = split;
+  if (tile < hp.n_tiles) fetch(tile);
+  for (; tile < hp.n_tiles; tile += hp.splits) {
+    __syncthreads();                                          // the previous tile's fragments are all read
+    stage();
+    __syncthreads();
+    if (tile + hp.splits < hp.n_tiles) fetch(tile + hp.splits);   // in flight under the MFMAs below
+#pragma unroll 1
+    for (int ks = 0; ks < 4; ++ks) {                          // k-step = 16 consecutive pixels of one tile row (not unrolled: 144
+                                                              // accumulator + 52 prefetch registers leave no room for hoisted fragments)
+      const int py = (ks * 16) / SW, px0 = (ks * 16) % SW;
+      bf16x8 af[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[pl] = frag(Ps + pl * P_PLANE, ks * 16 + l_pix, wr);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int hq = (py + kh) * HW_ + px0 + kw + l_pix;
+          bf16x8 bf[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bf[pl] = frag(Qs + pl * Q_PLANE, hq, wc);
+          f32x16& a9 = acc[kh * 3 + kw];
+          // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of wgrad_bf3_kernel
+          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], a9, 0, 0, 0);
+          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], a9, 0, 0, 0);
+          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], a9, 0, 0, 0);
+          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], a9, 0, 0, 0);
+          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], a9, 0, 0, 0);
+          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], a9, 0, 0, 0);
+        }
+    }
+  }
+  // this workgroup's 64 x 9 x 64 block of the partial slab of its split: [R][9][C]
+  float* out = ws + (size_t)split * R * 9 * C;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = r0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      out[((size_t)rr * 9 + t) * C + c0 + wc * 32 + fr] = acc[t][r];
+    }
+}
+
+Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
+  Halo9Plan h = {false, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (d->KH != 3 || d->KW != 3 || d->pad_h != 1 || d->pad_w != 1 || d->stride_h != 1 || d->stride_w != 1 || d->PH != d->QH || d->PW != d->QW) return h;
+  if (d->R % 64 || d->C % 64) return h;
+  h.sw = (d->PW % 32 == 0) ? 32 : (d->PW == 16 ? 16 : 0);
+  if (!h.sw) return h;
+  h.th = 64 / h.sw;
+  if (d->PH % h.th) return h;
+  h.tiles_x = d->PW / h.sw;
+  h.tiles_y = d->PH / h.th;
+  const long long nt = (long long)d->B * h.tiles_x * h.tiles_y;
+  if (nt > 0x7fffffffLL) return h;
+  h.n_tiles = (int)nt;
+  h.r_blks = d->R / 64;
+  h.c_blks = d->C / 64;
+  // two workgroups per CU (77 KB of LDS each): about 512 workgroups, each walking at least 8 tiles
+  int splits = d->splits > 0 ? d->splits : 512 / (h.r_blks * h.c_blks);
+  if (splits > h.n_tiles / 8) splits = h.n_tiles / 8;
+  if (splits < 1) splits = 1;
+  h.splits = splits;
+  h.ok = true;
+  return h;
+}
+
+constexpr size_t H9_LDS = (size_t)3 * (64 + H9_HP_MAX) * 64 * 2;   // 76.8 KB
+
+// 64 x 64 channels is taken by both halo kernels: the split-bf16 nine-tap form wins (measured below) unless QEA_MFMA=f32
+bool prefer_halo9(const qea_wgrad_desc* d) { return qea_split_bf16_enabled() && d->R == 64 && d->C == 64 && halo9_plan(d).ok; }
+
+int launch_halo9(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
+  const long long grid = (long long)h.r_blks * h.c_blks * h.splits;
+  if (h.sw == 32) {
+    auto kern = wgrad_halo9_bf3_kernel<32>;
+    static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H9_LDS);
+    if (attr_rc != (int)hipSuccess) {
+      qea_set_error("qea_conv_wgrad: cannot reserve %zu bytes of LDS: %s", H9_LDS, hipGetErrorString((hipError_t)attr_rc));
+      return QEA_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), H9_LDS, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h);
+  } else {
+    auto kern = wgrad_halo9_bf3_kernel<16>;
+    static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H9_LDS);
+    if (attr_rc != (int)hipSuccess) {
+      qea_set_error("qea_conv_wgrad: cannot reserve %zu bytes of LDS: %s", H9_LDS, hipGetErrorString((hipError_t)attr_rc));
+      return QEA_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), H9_LDS, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h);
+  }
+  return QEA_OK;
+}
+
 }  // namespace
 
 extern "C" size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d) {
   if (!d || d->R <= 0 || d->C <= 0 || d->B <= 0) return 0;
-  if (d->tile == 0 || d->tile == 6) {
+  if ((d->tile == 0 && !prefer_halo9(d)) || d->tile == 6) {
     const HaloPlan h = halo_plan(d);
     if (h.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h.grid * h.wk);
+  }
+  if ((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23) {
+    const Halo9Plan h9 = halo9_plan(d);
+    if (h9.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h9.splits);
   }
   const Plan p = make_plan(d);
   if (p.splits <= 1) return 0;
@@ -779,7 +989,7 @@ extern "C" size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d) {
 extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
   int rc = validate(d, "qea_conv_wgrad");
   if (rc != QEA_OK) return rc;
-  if (d->tile == 0 || d->tile == 6) {
+  if ((d->tile == 0 && !prefer_halo9(d)) || d->tile == 6) {
     const HaloPlan h = halo_plan(d);
     if (h.ok) {
       const size_t slab = (size_t)d->R * 9 * d->C;
@@ -800,6 +1010,25 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
       return QEA_OK;
     }
     QEA_REQUIRE(d->tile == 0, "qea_conv_wgrad: tile 6 (LDS-halo) needs a 3x3 pad-1 stride-1 conv with R,C in {32,64}, PW %% 32 == 0");
+  }
+  if ((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23) {
+    const Halo9Plan h9 = halo9_plan(d);
+    if (h9.ok) {
+      const size_t slab = (size_t)d->R * 9 * d->C;
+      const size_t need9 = slab_workspace_bytes(slab, h9.splits);
+      QEA_REQUIRE(d->workspace && d->workspace_bytes >= need9 && ((uintptr_t)d->workspace & 15) == 0,
+                  "qea_conv_wgrad: workspace of %zu bytes required, %zu given", need9, (size_t)d->workspace_bytes);
+      hipStream_t hs = (hipStream_t)stream;
+      qea_prof_begin(QEA_PROF_CONV_WGRAD, hs);
+      rc = launch_halo9(d, h9, hs);
+      if (rc != QEA_OK) return rc;
+      reduce_slabs((float*)d->workspace, d->dw, (long long)slab / 4, h9.splits, d->accumulate, hs);
+      qea_prof_end(QEA_PROF_CONV_WGRAD, hs, 2.0 * d->B * d->PH * (double)d->PW * (double)slab,
+                   4.0 * ((double)d->B * d->PH * d->PW * d->R + (double)d->B * d->QH * d->QW * d->C + (double)slab), true);
+      QEA_CHECK_LAUNCH();
+      return QEA_OK;
+    }
+    QEA_REQUIRE(d->tile == 0, "qea_conv_wgrad: tile 23 (nine-tap split-bf16) needs a 3x3 pad-1 stride-1 conv, R,C multiples of 64, PW in {16, 32k}");
   }
   const Plan p = make_plan(d);
   const size_t need = (p.splits > 1) ? slab_workspace_bytes((size_t)d->R * d->KH * d->KW * d->C, p.splits) : 0;

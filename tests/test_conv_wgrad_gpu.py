@@ -73,3 +73,27 @@ def test_wgrad_linear():
     ops.conv_wgrad(dy.cuda(), x.cuda(), dw, B=1, PH=1, PW=M, QH=1, QW=M, R=N, Cc=K, KH=1, KW=1, ldp=N, ldq=K)
     torch.cuda.synchronize()
     assert (dw.cpu().double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 32, 128, 128), (3, 8, 32, 256, 128), (5, 4, 16, 128, 256), (2, 4, 32, 256, 512),
+                                            (2, 16, 64, 64, 128), (1, 4, 32, 512, 512), (9, 4, 16, 256, 256)])
+@pytest.mark.parametrize("splits", [0, 1, 3])
+def test_wgrad_nine_tap_split_bf16(B, H, W, Cin, Cout, splits):
+    """tile 23 = wgrad_halo9_bf3_kernel: a workgroup accumulates all nine taps of a 64x64 channel block from ONE staged
+    dY tile + X halo (split once) instead of gathering and splitting both operands per tap; 32- and 16-pixel-wide tiles,
+    image borders, pixel splits (order-fixed slab reduction), accumulate; against torch-CPU autograd in fp64."""
+    _conv_case(B, H, W, Cin, Cout, tile=23, splits=splits, seed=B * 100 + H, accumulate=(splits == 3))
+
+
+def test_wgrad_nine_tap_bit_reproducible_and_default():
+    from qea import ops
+    g = torch.Generator().manual_seed(3)
+    Bn, Hh, Ww, Ci, Co = 64, 8, 32, 128, 256
+    x = torch.randn(Bn, Hh, Ww, Ci, generator=g).cuda()
+    dy = torch.randn(Bn, Hh, Ww, Co, generator=g).cuda()
+    outs = []
+    for tile in (23, 23, 0):                                   # tile 0 (auto) must take the nine-tap kernel for this shape
+        dw = torch.empty(Co, 3, 3, Ci, device="cuda")
+        ops.conv_wgrad(dy, x, dw, B=Bn, PH=Hh, PW=Ww, QH=Hh, QW=Ww, R=Co, Cc=Ci, KH=3, KW=3, pad=(1, 1), ldp=Co, ldq=Ci, tile=tile)
+        outs.append(dw.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
