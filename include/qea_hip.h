@@ -102,11 +102,17 @@ typedef struct qea_conv_desc {
    * by qea_split_planes: x_planes from x (M = B*H*W rows, Cin channels), w_planes from w (N rows, K = KH*KW*Cin).   */
   const void* x_planes;
   const void* w_planes;
+  /* ABI v3: fused BatchNorm batch statistics.  When non-NULL the launch also writes, per partial block k and output column
+   * n, stats[(k*N + n)*2 + {0,1}] = fp64 sum / sum of squares of the stored outputs of that block's rows;
+   * qea_conv_igemm_stats_blocks(d) gives the block count (0: this launch has no such epilogue — run qea_bn_train_stats).
+   * qea_bn_train_stats_from_partials turns the partials into the BatchNorm coefficients. */
+  double* stats;
 } qea_conv_desc;
 
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
 /* 1 when qea_conv_igemm would run this launch on a split-bf16 tile (so that pre-split operands pay), else 0 */
 int qea_conv_igemm_uses_split_bf16(const qea_conv_desc* d);
+int qea_conv_igemm_stats_blocks(const qea_conv_desc* d);
 
 /* P3 format of a fp32 matrix [M][ld] with C used columns (C % 16 == 0): planes[row][C/16][3][16] bf16 — per 16-column
  * slice the three bf16 planes h, m, l of x = h + m + l (|x - (h+m+l)| <= 2^-24 |x|), 96 contiguous bytes — followed by
@@ -167,6 +173,11 @@ int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_t C, const 
                        float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
                        float* invstd_out, float* scale_out, float* shift_out, double* stat64, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* the same, from the per-block partial sums a convolution's fused-statistics epilogue wrote (qea_conv_desc.stats) */
+int qea_bn_train_stats_from_partials(const double* partials, int32_t blocks, int64_t M, int32_t C, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                     float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* stat64,
+                                     void* stream);
 int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, const float* conv_bias, float* mean_out,
                       float* invstd_out, float* scale_out, float* shift_out, void* stream);

@@ -30,13 +30,24 @@ struct ConvArgs {
   const char* xp;
   const char* wp;
   unsigned xp_zero, wp_zero;
+  // fused BatchNorm batch statistics (STATS kernels): per (M-tile, wave row) partial column sums [blocks][N][2] in fp64
+  double* stats;
 };
 
 // Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Order: v = acc*scale + bias; relu; mask; accumulate; store (out_mode remaps).
-template <int MI, int NJ, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&acc)[MI][NJ], int m0, int n0, int wm, int wn, int fr, int fh) {
+// STATS: additionally accumulate, per output column, sum and sum of squares of the STORED values in fp64 (rows past M hold
+// zero accumulators and add nothing) and write one partial per (M-tile, wave row): the batch statistics of the BatchNorm
+// that follows (models/model_unet.py:78-109) without a second pass over the conv output.
+template <int MI, int NJ, int TM, int TN, bool STATS = false>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&acc)[MI][NJ], int m0, int n0, int wm, int wn, int fr, int fh,
+                                              int stats_block = 0) {
   const int ohw = p.OH * p.OW;
+  double st0[NJ], st1[NJ];
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) st0[j] = st1[j] = 0.0;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -84,6 +95,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
         }
         if (p.accumulate) v += p.y[o];
         p.y[o] = v;
+        if (STATS) {
+          st0[j] += (double)v;
+          st1[j] += (double)v * (double)v;
+        }
+      }
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      // the two lane halves hold different rows of the same column
+      const double a = st0[j] + __shfl_xor(st0[j], 32, 64);
+      const double b = st1[j] + __shfl_xor(st1[j], 32, 64);
+      const int n = n0 + wn * TN + j * 32 + fr;
+      if (fh == 0 && n < p.N) {
+        double* dst = p.stats + ((size_t)stats_block * p.N + n) * 2;
+        dst[0] = a;
+        dst[1] = b;
       }
     }
   }
@@ -578,7 +607,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // of the staging work — a third of it on the 256x128 tile, two thirds on 128x256 — leaves the VALU for free.
 // Same LDS image and MFMA sequence as the other two kernels: bit-identical results.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool STATS>
 __global__ __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(WGM * WGN == 8 ? 4 : 1)))
 void conv_igemm_bf3w_kernel(const ConvArgs p) {
   constexpr int BK = 16;
@@ -700,16 +729,16 @@ void conv_igemm_bf3w_kernel(const ConvArgs p) {
     if (kt + 1 < KT) stage_a(cur ^ 1);
     __syncthreads();
   }
-  conv_epilogue<MI, NJ, TM, TN>(p, acc, m0, n0, wm, wn, fr, fh);
+  conv_epilogue<MI, NJ, TM, TN, STATS>(p, acc, m0, n0, wm, wn, fr, fh, tile_m * WGM + wm);
 }
 
-template <int BM, int BN, int WGM, int WGN>
-int launch_bf3w(const ConvArgs& a, hipStream_t s) {
+template <int BM, int BN, int WGM, int WGN, bool STATS>
+int launch_bf3w_(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.m_tiles = qea_cdiv(p.M, BM);
   p.n_tiles = qea_cdiv(p.N, BN);
   const size_t lds = (size_t)2 * 3 * (BM + BN) * 16 * 2;
-  auto kern = conv_igemm_bf3w_kernel<BM, BN, WGM, WGN>;
+  auto kern = conv_igemm_bf3w_kernel<BM, BN, WGM, WGN, STATS>;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr_rc != (int)hipSuccess) {
     qea_set_error("qea_conv_igemm: cannot reserve %zu bytes of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString((hipError_t)attr_rc));
@@ -722,6 +751,11 @@ int launch_bf3w(const ConvArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
   return QEA_OK;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_bf3w(const ConvArgs& a, hipStream_t s) {
+  return a.stats ? launch_bf3w_<BM, BN, WGM, WGN, true>(a, s) : launch_bf3w_<BM, BN, WGM, WGN, false>(a, s);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -797,10 +831,11 @@ int launch(const ConvArgs& a, hipStream_t s) {
 // with shifted addresses; filter fragments come straight from global memory (<= 147 KB, L1/L2-resident),
 // so after the single barrier the four waves never synchronise again.
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int TH>
+template <int CIN, int COUT, int TH, bool STATS>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            float* __restrict__ y, int B, int H, int W, int ldx, int ldy,
-                                                           const float* __restrict__ scale, const float* __restrict__ bias, int relu) {
+                                                           const float* __restrict__ scale, const float* __restrict__ bias, int relu,
+                                                           double* __restrict__ stats) {
   constexpr int TW = 32, PS = CIN + 4, HW_ = TW + 2, HH = TH + 2;
   constexpr int MI = TH / 4, NJ = COUT / 32, KC = CIN / 32;
   extern __shared__ __attribute__((aligned(16))) float halo[];  // [HH][HW_][PS]
@@ -892,6 +927,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restri
     esc[j] = scale ? scale[j * 32 + fr] : 1.f;
     ebi[j] = bias ? bias[j * 32 + fr] : 0.f;
   }
+  double st0[NJ], st1[NJ];
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) st0[j] = st1[j] = 0.0;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float* yrow = y + ((size_t)(b * H + y0 + wave * MI + i) * W + x0) * ldy;
@@ -906,15 +946,31 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const float* __restri
         else if (bias) v += ebi[j];
         if (relu) v = fmaxf(v, 0.f);
         yrow[(size_t)px * ldy + j * 32 + fr] = v;
+        if (STATS) {
+          st0[j] += (double)v;
+          st1[j] += (double)v * (double)v;
+        }
+      }
+    }
+  }
+  if (STATS) {                                   // one partial per (workgroup, wave): [blocks][COUT][2] fp64 column sums
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const double a = st0[j] + __shfl_xor(st0[j], 32, 64);
+      const double c = st1[j] + __shfl_xor(st1[j], 32, 64);
+      if (fh == 0) {
+        double* dst = stats + ((size_t)(blockIdx.x * 4 + wave) * COUT + j * 32 + fr) * 2;
+        dst[0] = a;
+        dst[1] = c;
       }
     }
   }
 }
 
-template <int CIN, int COUT, int TH>
-int launch_halo(const ConvArgs& a, hipStream_t s) {
+template <int CIN, int COUT, int TH, bool STATS>
+int launch_halo_(const ConvArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)(TH + 2) * 34 * (CIN + 4) * sizeof(float);
-  auto kern = conv3x3_halo_kernel<CIN, COUT, TH>;
+  auto kern = conv3x3_halo_kernel<CIN, COUT, TH, STATS>;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr_rc != (int)hipSuccess) {
     qea_set_error("qea_conv_igemm(halo): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
@@ -925,8 +981,13 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
     qea_set_error("qea_conv_igemm(halo): grid %lld out of range", grid);
     return QEA_ERR_INVALID;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, a.w, a.y, a.B, a.H, a.W, a.ldx, a.ldy, a.scale, a.bias, a.relu);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, a.w, a.y, a.B, a.H, a.W, a.ldx, a.ldy, a.scale, a.bias, a.relu, a.stats);
   return QEA_OK;
+}
+
+template <int CIN, int COUT, int TH>
+int launch_halo(const ConvArgs& a, hipStream_t s) {
+  return a.stats ? launch_halo_<CIN, COUT, TH, true>(a, s) : launch_halo_<CIN, COUT, TH, false>(a, s);
 }
 
 bool halo_eligible(const qea_conv_desc* d) {
@@ -976,7 +1037,34 @@ int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
   return tile;
 }
 
+// Partial blocks the fused-statistics epilogue of this launch writes, 0 when the chosen kernel has none: the hybrid
+// split-bf16 tiles (one block per M-tile and wave row) and the fp32 LDS-halo kernel (one per workgroup and wave); the output
+// must be the plain conv result (no scale / bias / ReLU / mask / accumulate, NHWC).
+int stats_blocks_for(const qea_conv_desc* d, const ConvArgs& a, int tile, bool wp3) {
+  if (d->scale || d->bias || d->mask || d->relu || d->accumulate || d->out_mode != QEA_OUT_NHWC) return 0;
+  if (tile == 4 && halo_eligible(d)) return d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32) * 4;
+  if (!wp3) return 0;
+  switch (tile) {
+    case 21: return qea_cdiv(a.M, 256) * 4;
+    case 22: return qea_cdiv(a.M, 128) * 2;
+    case 23: return qea_cdiv(a.M, 256) * 4;
+    case 25: return qea_cdiv(a.M, 128) * 4;
+    default: return 0;
+  }
+}
+
 }  // namespace
+
+extern "C" int qea_conv_igemm_stats_blocks(const qea_conv_desc* d) {
+  if (!d || d->Cin <= 0 || d->Cin % 32 || d->B <= 0) return 0;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = d->B * d->OH * d->OW;
+  a.N = d->N;
+  a.K = d->KH * d->KW * d->Cin;
+  const int tile = d->tile ? d->tile : pick_tile(d, a);
+  return stats_blocks_for(d, a, tile, tile >= 20 && !d->x_planes && d->w_planes);
+}
 
 extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   QEA_REQUIRE(d && d->x && d->w && d->y, "qea_conv_igemm: null pointer");
@@ -1008,6 +1096,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   a.xp = (const char*)d->x_planes;
   a.wp = (const char*)d->w_planes;
   a.xp_zero = a.wp_zero = 0;
+  a.stats = nullptr;
 
   hipStream_t s = (hipStream_t)stream;
   int tile = d->tile ? d->tile : pick_tile(d, a);
@@ -1024,6 +1113,11 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     QEA_REQUIRE(((uintptr_t)d->x_planes & 15) == 0 && ((uintptr_t)d->w_planes & 15) == 0, "qea_conv_igemm: planes must be 16-byte aligned");
     a.xp_zero = (unsigned)xb;
     a.wp_zero = (unsigned)wb;
+  }
+  if (d->stats) {
+    const int blocks = stats_blocks_for(d, a, tile, wp3);
+    QEA_REQUIRE(blocks > 0, "qea_conv_igemm: this launch cannot produce fused statistics (ask qea_conv_igemm_stats_blocks first)");
+    a.stats = d->stats;
   }
   qea_prof_begin(QEA_PROF_CONV_IGEMM, s);
   int rc;

@@ -430,6 +430,18 @@ extern "C" int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_
   return QEA_OK;
 }
 
+extern "C" int qea_bn_train_stats_from_partials(const double* partials, int32_t blocks, int64_t M, int32_t C, const float* gamma,
+                                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                                float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* stat64,
+                                                void* stream) {
+  QEA_REQUIRE(partials && blocks > 0 && M > 0 && C > 0 && mean_out && invstd_out && scale_out && shift_out,
+              "qea_bn_train_stats_from_partials: bad arguments");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, blocks, C, (long long)M,
+                     gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, stat64);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
 extern "C" int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                  float eps, const float* conv_bias, float* mean_out, float* invstd_out, float* scale_out,
                                  float* shift_out, void* stream) {

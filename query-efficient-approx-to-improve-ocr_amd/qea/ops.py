@@ -50,6 +50,7 @@ def split_planes(x, ld, M, Cc):
     return out
 
 
+FUSE_BN_STATS = {"on": True}     # tests switch the fused statistics epilogue off to compare with the separate pass
 PRESPLIT = {"on": True, "x": False}     # tests / tools: "on" = pre-split filters (default), "x" = pre-split activations too
 
 # ---- derived forms of WEIGHTS (dgrad filter layouts, transposes, P3 planes), kept until the weights change.
@@ -102,11 +103,13 @@ def transposed(w, R, Cc):
 
 def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(1, 1), ldx, ldy,
                scale=None, bias=None, mask=None, ldmask=0, relu=False, accumulate=False,
-               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None):
+               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None, want_stats=False):
     """x_planes / w_planes: operands already in the P3 format (a caller that uses a tensor in several launches splits it
     once); when the launch runs on a split-bf16 tile and they are not given, they are made here (one HBM pass each).
     w_src = (kind, weight tensor): `w` is a function of that weight only (itself: kind "fwd"; its cached flip_transposed /
-    transposed form: "flipT" / "T"), so its planes are cached with it until the weight changes."""
+    transposed form: "flipT" / "T"), so its planes are cached with it until the weight changes.
+    want_stats: ask for the fused BatchNorm-statistics epilogue; returns (partials [blocks][N][2] fp64, blocks) when the chosen
+    kernel has it, else None (the caller then runs bn_train_stats over y)."""
     L = _lib.lib()
     d = _lib.ConvDesc(x=_ptr(x), w=_ptr(w), y=_ptr(y), scale=_ptr(scale), bias=_ptr(bias), mask=_ptr(mask),
                       B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW, N=N, KH=KH, KW=KW, pad_h=pad[0], pad_w=pad[1],
@@ -126,7 +129,14 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
                     w_planes = split_planes(w, K, N, K)
             d.x_planes = x_planes.data_ptr() if x_planes is not None else None
             d.w_planes = w_planes.data_ptr()
+    partials = None
+    if want_stats and FUSE_BN_STATS["on"]:
+        blocks = L.qea_conv_igemm_stats_blocks(C.byref(d))
+        if blocks > 0:
+            partials = torch.empty(blocks, N, 2, dtype=torch.float64, device=x.device)
+            d.stats = partials.data_ptr()
     _lib.check(L.qea_conv_igemm(C.byref(d), _stream()), "qea_conv_igemm")
+    return (partials, partials.shape[0]) if partials is not None else None
 
 
 def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride=(1, 1), ldp, ldq,
@@ -237,6 +247,14 @@ def bn_train_stats(y, ldy, M, C_, gamma, beta, eps, momentum, running_mean, runn
     _lib.check(_lib.lib().qea_bn_train_stats(_ptr(y), ldy, M, C_, _ptr(gamma), _ptr(beta), eps, momentum,
                                              _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
                                              _ptr(scale), _ptr(shift), _ptr(stat64), wp, wn, _stream()), "qea_bn_train_stats")
+
+
+def bn_train_stats_from_partials(partials, blocks, M, C_, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
+                                 stat64=None):
+    _lib.check(_lib.lib().qea_bn_train_stats_from_partials(_ptr(partials), blocks, M, C_, _ptr(gamma), _ptr(beta), eps, momentum,
+                                                           _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
+                                                           _ptr(scale), _ptr(shift), _ptr(stat64), _stream()),
+               "qea_bn_train_stats_from_partials")
 
 
 def bn_eval_coeff(C_, gamma, beta, running_mean, running_var, eps, conv_bias, mean, invstd, scale, shift):

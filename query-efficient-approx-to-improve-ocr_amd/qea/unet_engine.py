@@ -66,17 +66,24 @@ class UNetEngine:
                            scale=coef[2], bias=coef[3], relu=True, w_src=("fwd", w))
             return
         y = torch.empty(M, cout, device=dev)
+        fused = None
         if cin == 1:
             ops.conv_c1_fwd(x, w, None, y, cout, B, H, W, cout, relu=False)
         else:
-            ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=cout, w_src=("fwd", w))
+            # train-mode BatchNorm: the conv's epilogue also leaves per-block fp64 column sums of y (no second pass over y)
+            fused = ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=cout,
+                                   w_src=("fwd", w), want_stats=training)
         coef = torch.empty(4, cout, device=dev)  # mean, invstd, scale, shift
         stat64 = None
         gamma, beta = P[blk.key(i, "gamma")], P[blk.key(i, "beta")]
         rm, rv = Bf[blk.key(i, "rm")], Bf[blk.key(i, "rv")]
         if training:
             stat64 = torch.empty(2, cout, device=dev, dtype=torch.float64) if saved is not None else None
-            ops.bn_train_stats(y, cout, M, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[0], coef[1], coef[2], coef[3], stat64)
+            if fused is not None:
+                ops.bn_train_stats_from_partials(fused[0], fused[1], M, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[0], coef[1],
+                                                 coef[2], coef[3], stat64)
+            else:
+                ops.bn_train_stats(y, cout, M, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[0], coef[1], coef[2], coef[3], stat64)
         else:
             ops.bn_eval_coeff(cout, gamma, beta, rm, rv, BN_EPS, None, coef[0], coef[1], coef[2], coef[3])
         ops.bn_apply(y, cout, out, ldo, M, cout, coef[2], coef[3], relu=True)

@@ -202,3 +202,42 @@ def test_non_finite_operand_stays_confined_and_visible():
         assert torch.isfinite(clean).all()
         assert (~torch.isfinite(bad[hit])).all(), mode
         assert torch.equal(bad[~hit], clean[~hit]), mode
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 32, 128, 128), (2, 4, 32, 256, 512), (5, 16, 64, 64, 64), (3, 32, 128, 32, 32), (2, 16, 64, 32, 64),
+                                   (7, 4, 16, 256, 256), (3, 2, 8, 512, 512), (2, 16, 64, 128, 64)])
+def test_fused_bn_statistics_epilogue(shape):
+    """batch statistics of the BatchNorm that follows a conv (models/model_unet.py:78-109) as per-block fp64
+    column sums from the conv's own epilogue.  The conv output is bit-identical with and without the epilogue, and mean /
+    invstd / scale / shift / running statistics equal those of the separate pass over y (same fp64 sums up to their order)."""
+    from qea import ops
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(H + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(Cout, generator=g)).cuda(), (0.1 * torch.randn(Cout, generator=g)).cuda()
+    M = B * H * W
+    res = {}
+    for fuse in (False, True):
+        ops.FUSE_BN_STATS["on"] = fuse
+        try:
+            y = torch.empty(M, Cout, device="cuda")
+            got = ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad=(1, 1), ldx=Cin, ldy=Cout, want_stats=True)
+        finally:
+            ops.FUSE_BN_STATS["on"] = True
+        coef = torch.empty(4, Cout, device="cuda")
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        st = torch.empty(2, Cout, device="cuda", dtype=torch.float64)
+        if fuse:
+            assert got is not None, "every shape here runs on a kernel with the statistics epilogue"
+            ops.bn_train_stats_from_partials(got[0], got[1], M, Cout, gamma, beta, 1e-5, 0.1, rm, rv, coef[0], coef[1], coef[2], coef[3], st)
+        else:
+            assert got is None
+            ops.bn_train_stats(y, Cout, M, Cout, gamma, beta, 1e-5, 0.1, rm, rv, coef[0], coef[1], coef[2], coef[3], st)
+        res[fuse] = (y, coef, rm, rv, st)
+    torch.cuda.synchronize()
+    assert torch.equal(res[False][0], res[True][0])
+    yd = res[True][0].double()
+    assert (res[True][4][0] - yd.mean(0)).abs().max().item() <= 1e-12 * max(1.0, yd.abs().max().item())
+    for a, b in zip(res[False][1:], res[True][1:]):
+        assert (a.double() - b.double()).abs().max().item() <= 2e-7 * max(1.0, a.double().abs().max().item())
