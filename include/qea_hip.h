@@ -107,12 +107,18 @@ typedef struct qea_conv_desc {
    * qea_conv_igemm_stats_blocks(d) gives the block count (0: this launch has no such epilogue — run qea_bn_train_stats).
    * qea_bn_train_stats_from_partials turns the partials into the BatchNorm coefficients. */
   double* stats;
+  /* ABI v4: filter of a narrow 3x3 layer (Cin, N in {32, 64}) as bf16 planes in MFMA-fragment order (qea_pack_frag_planes):
+   * operand of the split-bf16 LDS-halo kernel (tile 24); without it such a launch runs on the fp32 halo / generic tiles. */
+  const void* w_frag_planes;
 } qea_conv_desc;
 
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
 /* 1 when qea_conv_igemm would run this launch on a split-bf16 tile (so that pre-split operands pay), else 0 */
 int qea_conv_igemm_uses_split_bf16(const qea_conv_desc* d);
 int qea_conv_igemm_stats_blocks(const qea_conv_desc* d);
+int qea_conv_igemm_wants_frag_planes(const qea_conv_desc* d);
+size_t qea_pack_frag_planes_bytes(int32_t N, int32_t Cin);
+int qea_pack_frag_planes(const float* w, int32_t N, int32_t Cin, void* planes, void* stream);
 
 /* P3 format of a fp32 matrix [M][ld] with C used columns (C % 16 == 0): planes[row][C/16][3][16] bf16 — per 16-column
  * slice the three bf16 planes h, m, l of x = h + m + l (|x - (h+m+l)| <= 2^-24 |x|), 96 contiguous bytes — followed by

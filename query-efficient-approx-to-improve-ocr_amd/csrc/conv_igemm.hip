@@ -990,12 +990,214 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
   return a.stats ? launch_halo_<CIN, COUT, TH, true>(a, s) : launch_halo_<CIN, COUT, TH, false>(a, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 form of conv3x3_halo_kernel for the NARROW layers (C_in, C_out in {32, 64}; tile 24).  Seventeen per cent of
+// a B = 2048 step still ran on the fp32 MFMA (105-120 TFLOP/s) or on the 256x64 generic split tile (150), which gathers
+// and splits every input element once per tap.  Here the (TH+2) x 34 input halo of a TH x 32 pixel tile is gathered ONCE,
+// split ONCE into the three bf16 planes and kept in LDS for all nine taps and all channel slices; the filter comes from its
+// cached planes in MFMA-fragment order (qea_pack_frag_planes: one coalesced 1 KiB wave load per fragment, L1/L2-resident,
+// next step's fragments in flight under this step's MFMAs); six v_mfma_f32_32x32x16_bf16 per product in the order of the
+// other split kernels.  LDS rows = pixels x C_in bf16, the 16-byte slots of pixel p stored at slot ^ ((p >> s) & m) so
+// that the 16 pixels of a ds_read_b128 lane group fall on distinct slots of the 256-byte bank row.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int TH, bool STATS>
+__global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
+                                                               int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
+                                                               const float* __restrict__ bias, int relu, double* __restrict__ stats) {
+  constexpr int TW = 32, HW_ = TW + 2, HH = TH + 2, HP = HH * HW_;
+  constexpr int WN = COUT / 32, WM = 4 / WN;            // waves across output channels / across tile rows
+  constexpr int MI = TH / WM;                           // 32-pixel rows per wave
+  constexpr int KS = CIN / 16;                          // 16-channel MFMA k-steps per tap
+  constexpr int SLOTS = CIN / 8;                        // 16-byte slots per pixel row (4 or 8)
+  constexpr int PLANE = HP * CIN;                       // bf16 elements per plane
+  static_assert(MI >= 1 && TH % WM == 0, "tile rows must split over the waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem);         // [3][HP][CIN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+
+  // slot swizzle: 64-byte rows (CIN 32) put 4 pixels in a bank row -> key (p >> 2) & 3; 128-byte rows (CIN 64): 2 pixels -> (p >> 1) & 7
+  auto swz = [](int p, int slot) { return SLOTS == 4 ? (slot ^ ((p >> 2) & 3)) : (slot ^ ((p >> 1) & 7)); };
+
+  // ---- halo: gather (zero outside the image), split once, three planes into LDS
+  constexpr int C4 = CIN / 4;
+  constexpr int NLD = (HP * C4 + 255) / 256;
+  const float* xb = x + (size_t)b * H * W * ldx;
+  f32x4 hv[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i;
+    const int c4 = e % C4, q = e / C4;
+    const int hx = q % HW_, hy = q / HW_;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    const bool ok = e < HP * C4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)iy * W + ix) * ldx + c4 * 4 : x);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    hv[i] = ok ? v : zero;
+  }
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i;
+    if (e < HP * C4) {
+      const int c4 = e % C4, q = e / C4;
+      bf16x4 h, m, l;
+      qea_split3(hv[i], h, m, l);
+      const int o = q * CIN + swz(q, c4 >> 1) * 8 + (c4 & 1) * 4;
+      *reinterpret_cast<bf16x4*>(As + o) = h;
+      *reinterpret_cast<bf16x4*>(As + PLANE + o) = m;
+      *reinterpret_cast<bf16x4*>(As + 2 * PLANE + o) = l;
+    }
+  }
+  __syncthreads();
+
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16 acc[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // filter fragments: wf[step = tap*KS + cs][plane][nj][lane][8]; this wave's nj = wn
+  constexpr int STEPS = 9 * KS;
+  const bf16x8* wl = reinterpret_cast<const bf16x8*>(wf) + wn * 64 + lane;
+  bf16x8 bq[2][3];
+  auto load_b = [&](int st, int buf) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) bq[buf][pl] = wl[(size_t)(st * 3 + pl) * WN * 64];
+  };
+  load_b(0, 0);
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < STEPS) load_b(st + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);                  // keep the next step's filter loads AHEAD of this step's MFMAs
+    const int tap = st / KS, cs = st % KS;
+    const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int hp = (wm * MI + i + kh) * HW_ + fr + kw;
+      const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + PLANE);
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
+      // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[cur][0], acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][2], acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cur][1], acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cur][0], acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][1], acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][0], acc[i], 0, 0, 0);
+    }
+  }
+
+  // ---- store: row (= pixel x) = (r&3) + 8*(r>>2) + 4*fh, col (= channel) = wn*32 + fr
+  const int n = wn * 32 + fr;
+  const float esc = scale ? scale[n] : 1.f, ebi = bias ? bias[n] : 0.f;
+  double st0 = 0.0, st1 = 0.0;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float* yrow = y + ((size_t)(b * H + y0 + wm * MI + i) * W + x0) * ldy;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
+      float v = acc[i][r];
+      if (scale && bias) v = __fmaf_rn(v, esc, ebi);
+      else if (scale) v *= esc;
+      else if (bias) v += ebi;
+      if (relu) v = fmaxf(v, 0.f);
+      yrow[(size_t)px * ldy + n] = v;
+      if (STATS) {
+        st0 += (double)v;
+        st1 += (double)v * (double)v;
+      }
+    }
+  }
+  if (STATS) {                                          // one partial per (workgroup, wave row): [blocks][COUT][2]
+    const double a = st0 + __shfl_xor(st0, 32, 64);
+    const double c = st1 + __shfl_xor(st1, 32, 64);
+    if (fh == 0) {
+      double* dst = stats + ((size_t)(blockIdx.x * WM + wm) * COUT + n) * 2;
+      dst[0] = a;
+      dst[1] = c;
+    }
+  }
+}
+
+// w [N][9][CIN] fp32 (N = 32 or 64 rows) -> fragment-ordered planes [step = tap*KS + cs][plane][nj][lane][8 bf16]:
+// lane (n = nj*32 + (lane & 31), half = lane >> 5) holds channels cs*16 + 8*half + j of filter row n at `tap`
+__global__ void pack_frag_planes_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int N, int CINr) {
+  const int KSr = CINr / 16, WNr = N / 32;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;         // (step, nj, lane)
+  if (i >= 9 * KSr * WNr * 64) return;
+  const int lane = i & 63;
+  const int nj = (i >> 6) % WNr;
+  const int st = (i >> 6) / WNr;
+  const int tap = st / KSr, cs = st % KSr;
+  const int n = nj * 32 + (lane & 31);
+  const float* src = w + ((size_t)n * 9 + tap) * CINr + cs * 16 + 8 * (lane >> 5);
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+  bf16x4 h0, m0, l0, h1, m1, l1;
+  qea_split3(v0, h0, m0, l0);
+  qea_split3(v1, h1, m1, l1);
+  bf16x8 pl[3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pl[0][k] = h0[k]; pl[0][k + 4] = h1[k];
+    pl[1][k] = m0[k]; pl[1][k + 4] = m1[k];
+    pl[2][k] = l0[k]; pl[2][k + 4] = l1[k];
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + ((((size_t)st * 3 + p) * WNr + nj) * 64 + lane) * 8) = pl[p];
+}
+
+template <int CIN, int COUT, int TH, bool STATS>
+int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)3 * (TH + 2) * 34 * CIN * 2;
+  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS>;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_igemm(halo bf3): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
+  }
+  const long long grid = (long long)a.B * (a.H / TH) * (a.W / 32);
+  if (grid <= 0 || grid > 0x7fffffffLL) {
+    qea_set_error("qea_conv_igemm(halo bf3): grid %lld out of range", grid);
+    return QEA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy, a.scale, a.bias,
+                     a.relu, a.stats);
+  return QEA_OK;
+}
+
+template <int CIN, int COUT, int TH>
+int launch_halo_bf3(const ConvArgs& a, hipStream_t s) {
+  return a.stats ? launch_halo_bf3_<CIN, COUT, TH, true>(a, s) : launch_halo_bf3_<CIN, COUT, TH, false>(a, s);
+}
+
 bool halo_eligible(const qea_conv_desc* d) {
   const bool ch = (d->Cin == 32 || d->Cin == 64) && (d->N == 32 || d->N == 64);
   const int th = d->Cin == 32 ? 8 : 4;
   return ch && d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H &&
          d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->mask && !d->accumulate;
 }
+
+int launch_halo_bf3_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  if (d->Cin == 32 && d->N == 32) return launch_halo_bf3<32, 32, 8>(a, s);
+  if (d->Cin == 32 && d->N == 64) return launch_halo_bf3<32, 64, 8>(a, s);
+  if (d->Cin == 64 && d->N == 32) return launch_halo_bf3<64, 32, 4>(a, s);
+  return launch_halo_bf3<64, 64, 4>(a, s);
+}
+
+// workgroup-rows of the statistics partials: halo fp32 = 4 waves over rows; halo bf3 = WM = 4 / (COUT / 32)
+int halo_bf3_wm(const qea_conv_desc* d) { return 4 / (d->N / 32); }
 
 int launch_halo_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   if (d->Cin == 32 && d->N == 32) return launch_halo<32, 32, 8>(a, s);
@@ -1043,6 +1245,7 @@ int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
 int stats_blocks_for(const qea_conv_desc* d, const ConvArgs& a, int tile, bool wp3) {
   if (d->scale || d->bias || d->mask || d->relu || d->accumulate || d->out_mode != QEA_OUT_NHWC) return 0;
   if (tile == 4 && halo_eligible(d)) return d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32) * 4;
+  if (tile == 24 && halo_eligible(d)) return d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32) * halo_bf3_wm(d);
   if (!wp3) return 0;
   switch (tile) {
     case 21: return qea_cdiv(a.M, 256) * 4;
@@ -1100,6 +1303,9 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
 
   hipStream_t s = (hipStream_t)stream;
   int tile = d->tile ? d->tile : pick_tile(d, a);
+  if (tile == 24 && !d->tile && !d->w_frag_planes) {       // auto choice without the fragment-order planes: the previous choices
+    tile = (d->N > 32 && a.K >= 256 && d->Cin >= 64) ? 23 : 4;
+  }
   if (tile == 4 && !halo_eligible(d)) {
     qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate");
     return QEA_ERR_INVALID;
@@ -1123,6 +1329,14 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   int rc;
   switch (tile) {
     case 4: rc = launch_halo_any(d, a, s); break;
+    case 24:                                               // split-bf16 LDS-halo kernel of the narrow layers: filter in fragment-order planes
+      if (!halo_eligible(d) || !d->w_frag_planes) {
+        qea_set_error("qea_conv_igemm: tile 24 needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate, and w_frag_planes");
+        return QEA_ERR_INVALID;
+      }
+      a.wp = (const char*)d->w_frag_planes;
+      rc = launch_halo_bf3_any(d, a, s);
+      break;
     case 1: rc = launch<128, 128, 2, 2, 32>(a, s); break;
     case 2: rc = launch<256, 64, 4, 1, 32>(a, s); break;
     case 3: rc = launch<256, 32, 4, 1, 32>(a, s); break;
@@ -1170,4 +1384,26 @@ extern "C" int qea_split_planes(const float* x, int32_t ld, int64_t M, int32_t C
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (long long)M, C, (__bf16*)planes);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
+}
+
+extern "C" size_t qea_pack_frag_planes_bytes(int32_t N, int32_t Cin) { return (size_t)N * 9 * Cin * 6; }
+
+extern "C" int qea_pack_frag_planes(const float* w, int32_t N, int32_t Cin, void* planes, void* stream) {
+  QEA_REQUIRE(w && planes && (N == 32 || N == 64) && (Cin == 32 || Cin == 64), "qea_pack_frag_planes: N and Cin must be 32 or 64");
+  const int total = 9 * (Cin / 16) * (N / 32) * 64;
+  hipLaunchKernelGGL(pack_frag_planes_kernel, dim3(qea_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)planes, N, Cin);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+/* 2 when qea_conv_igemm would pick the narrow-layer split-bf16 LDS-halo kernel (tile 24: wants w_frag_planes), else 0 */
+extern "C" int qea_conv_igemm_wants_frag_planes(const qea_conv_desc* d) {
+  if (!d || d->Cin <= 0 || d->Cin % 32 || d->B <= 0) return 0;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = d->B * d->OH * d->OW;
+  a.N = d->N;
+  a.K = d->KH * d->KW * d->Cin;
+  const int tile = d->tile ? d->tile : pick_tile(d, a);
+  return tile == 24 ? 1 : 0;
 }

@@ -114,8 +114,18 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
     d = _lib.ConvDesc(x=_ptr(x), w=_ptr(w), y=_ptr(y), scale=_ptr(scale), bias=_ptr(bias), mask=_ptr(mask),
                       B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW, N=N, KH=KH, KW=KW, pad_h=pad[0], pad_w=pad[1],
                       stride_h=stride[0], stride_w=stride[1], ldx=ldx, ldy=ldy, ldmask=ldmask,
-                      relu=int(relu), accumulate=int(accumulate), out_mode=out_mode, tile=tile, x_planes=None, w_planes=None)
-    if PRESPLIT["on"] and Cin % 16 == 0 and L.qea_conv_igemm_uses_split_bf16(C.byref(d)):
+                      relu=int(relu), accumulate=int(accumulate), out_mode=out_mode, tile=tile, x_planes=None, w_planes=None, stats=None,
+                      w_frag_planes=None)
+    frag = None
+    if PRESPLIT["on"] and L.qea_conv_igemm_wants_frag_planes(C.byref(d)):
+        # narrow 3x3 layer on the split-bf16 LDS-halo kernel: its filter in fragment-order planes (a few hundred KB, cached)
+        def build():
+            out = torch.empty(L.qea_pack_frag_planes_bytes(N, Cin), dtype=torch.uint8, device=x.device)
+            _lib.check(L.qea_pack_frag_planes(_ptr(w), N, Cin, out.data_ptr(), _stream()), "qea_pack_frag_planes")
+            return out
+        frag = weight_cached(("frag", w_src[0], N, Cin), w_src[1], build) if w_src is not None else build()
+        d.w_frag_planes = frag.data_ptr()
+    elif PRESPLIT["on"] and Cin % 16 == 0 and L.qea_conv_igemm_uses_split_bf16(C.byref(d)):
         K = KH * KW * Cin
         if N * K * 6 < (1 << 31) - 256:
             # the FILTER's planes are made once per weight update and shared by every M-tile; an activation is consumed by one

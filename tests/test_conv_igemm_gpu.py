@@ -241,3 +241,43 @@ def test_fused_bn_statistics_epilogue(shape):
     assert (res[True][4][0] - yd.mean(0)).abs().max().item() <= 1e-12 * max(1.0, yd.abs().max().item())
     for a, b in zip(res[False][1:], res[True][1:]):
         assert (a.double() - b.double()).abs().max().item() <= 2e-7 * max(1.0, a.double().abs().max().item())
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,B", [(32, 32, 8, 32, 3), (32, 64, 16, 64, 2), (64, 32, 4, 32, 5), (64, 64, 12, 96, 2), (32, 32, 32, 128, 2),
+                                            (64, 64, 16, 64, 3)])
+def test_narrow_split_bf16_halo_kernel(Cin, Cout, H, W, B):
+    """tile 24 = conv3x3_halo_bf3_kernel (input halo split ONCE into bf16 planes in LDS, filter in fragment-order planes): against
+    fp64, against the fp32 LDS-halo kernel (tile 4), reading from / writing into wider (concat) buffers, with the fused
+    BatchNorm-statistics epilogue and with the scale / bias / ReLU epilogue."""
+    from qea import ops
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    ldx, ldy = Cin + 32, Cout + 64
+    xb = torch.full((B, H, W, ldx), 7.0, device="cuda")
+    xb[..., 32:] = x.permute(0, 2, 3, 1).cuda()
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    outs = {}
+    for tile in (4, 24):
+        yb = torch.full((B, H, W, ldy), -3.0, device="cuda")
+        got = ops.conv_igemm(xb[..., 32:], wd, yb[..., 64:], B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=ldy,
+                             tile=tile, want_stats=True)
+        torch.cuda.synchronize()
+        assert (yb[..., :64] == -3.0).all()
+        y = yb[..., 64:].cpu().permute(0, 3, 1, 2).double()
+        assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), tile
+        assert got is not None
+        part = got[0].sum(0).cpu()                                   # [Cout][2]
+        flat = yb[..., 64:].reshape(-1, Cout).double().cpu()
+        assert (part[:, 0] - flat.sum(0)).abs().max().item() <= 1e-9 * flat.abs().sum(0).max().item()
+        assert (part[:, 1] - (flat * flat).sum(0)).abs().max().item() <= 1e-9 * (flat * flat).sum(0).max().item()
+        outs[tile] = y
+    assert (outs[24] - outs[4]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # auto dispatch takes the split kernel; scale + bias + ReLU epilogue
+    sc, bi = torch.rand(Cout, generator=g).cuda() + 0.5, torch.randn(Cout, generator=g).cuda()
+    y2 = torch.empty(B, H, W, Cout, device="cuda")
+    ops.conv_igemm(xb[..., 32:], wd, y2, B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=Cout, scale=sc, bias=bi,
+                   relu=True)
+    want = (ref.permute(0, 2, 3, 1) * sc.cpu().double() + bi.cpu().double()).clamp_min(0)
+    assert (y2.cpu().double() - want).abs().max().item() <= 3e-5 * want.abs().max().item()

@@ -23,6 +23,8 @@ def main():
     tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
     L = _lib.lib()
     shapes = [sh for sh in SHAPES if sh[2] >= 64 and sh[3] >= 64] if len(sys.argv) > 3 and sys.argv[3] == "wide" else SHAPES
+    if len(sys.argv) > 3 and sys.argv[3] == "narrow":
+        shapes = [sh for sh in SHAPES if sh[2] <= 64 and sh[3] <= 64]
     s = torch.cuda.current_stream().cuda_stream
     tot_t = tot_f = 0.0
     for (H, W, Cin, Cout) in shapes:
@@ -33,13 +35,19 @@ def main():
         wp = torch.empty(L.qea_split_planes_bytes(Cout, 9 * Cin), dtype=torch.uint8, device="cuda")
         _lib.check(L.qea_split_planes(x.data_ptr(), Cin, B * H * W, Cin, xp.data_ptr(), s))
         _lib.check(L.qea_split_planes(w.data_ptr(), 9 * Cin, Cout, 9 * Cin, wp.data_ptr(), s))
+        narrow = Cin in (32, 64) and Cout in (32, 64)
+        fp = None
+        if narrow:
+            fp = torch.empty(L.qea_pack_frag_planes_bytes(Cout, Cin), dtype=torch.uint8, device="cuda")
+            _lib.check(L.qea_pack_frag_planes(w.data_ptr(), Cout, Cin, fp.data_ptr(), s))
         for tile in tiles:
             pre = 100 <= tile < 200                   # tile id + 100: the same tile on pre-split operands; + 200: pre-split FILTER only
             wonly = tile >= 200
             d = _lib.ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), scale=None, bias=None, mask=None,
                               B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad_h=1, pad_w=1,
                               stride_h=1, stride_w=1, ldx=Cin, ldy=Cout, ldmask=0, relu=0, accumulate=0,
-                              out_mode=0, tile=tile % 100, x_planes=xp.data_ptr() if pre else None, w_planes=wp.data_ptr() if (pre or wonly) else None)
+                              out_mode=0, tile=tile % 100, x_planes=xp.data_ptr() if pre else None, w_planes=wp.data_ptr() if (pre or wonly) else None,
+                              stats=None, w_frag_planes=fp.data_ptr() if (fp is not None and tile % 100 == 24) else None)
             if L.qea_conv_igemm(C.byref(d), s) != 0:     # a forced tile that does not take this shape
                 print(f"H{H:3d} W{W:3d} Cin{Cin:4d} Cout{Cout:4d} tile{tile}   n/a", flush=True)
                 continue
