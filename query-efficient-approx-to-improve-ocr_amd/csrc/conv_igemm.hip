@@ -1000,10 +1000,13 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
 // other split kernels.  LDS rows = pixels x C_in bf16, the 16-byte slots of pixel p stored at slot ^ ((p >> s) & m) so
 // that the 16 pixels of a ds_read_b128 lane group fall on distinct slots of the 256-byte bank row.
 // ---------------------------------------------------------------------------------------------
+// CIN is the channel CHUNK held in LDS at a time (32, or 64 for every wider input: `chunks` = C_in / 64 passes over the same
+// pixel tile, the next chunk's halo gathered into registers under this chunk's MFMAs); COUT in {32, 64, 128}.
 template <int CIN, int COUT, int TH, bool STATS>
 __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
-                                                               const float* __restrict__ bias, int relu, double* __restrict__ stats) {
+                                                               const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
+                                                               int Ntot) {
   constexpr int TW = 32, HW_ = TW + 2, HH = TH + 2, HP = HH * HW_;
   constexpr int WN = COUT / 32, WM = 4 / WN;            // waves across output channels / across tile rows
   constexpr int MI = TH / WM;                           // 32-pixel rows per wave
@@ -1027,36 +1030,39 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
   // slot swizzle: 64-byte rows (CIN 32) put 4 pixels in a bank row -> key (p >> 2) & 3; 128-byte rows (CIN 64): 2 pixels -> (p >> 1) & 7
   auto swz = [](int p, int slot) { return SLOTS == 4 ? (slot ^ ((p >> 2) & 3)) : (slot ^ ((p >> 1) & 7)); };
 
-  // ---- halo: gather (zero outside the image), split once, three planes into LDS
+  // ---- halo of one channel chunk: gather (zero outside the image), split once, three planes into LDS
   constexpr int C4 = CIN / 4;
   constexpr int NLD = (HP * C4 + 255) / 256;
   const float* xb = x + (size_t)b * H * W * ldx;
   f32x4 hv[NLD];
+  auto gather = [&](int chunk) {
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int e = tid + 256 * i;
-    const int c4 = e % C4, q = e / C4;
-    const int hx = q % HW_, hy = q / HW_;
-    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-    const bool ok = e < HP * C4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)iy * W + ix) * ldx + c4 * 4 : x);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    hv[i] = ok ? v : zero;
-  }
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int e = tid + 256 * i;
-    if (e < HP * C4) {
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i;
       const int c4 = e % C4, q = e / C4;
-      bf16x4 h, m, l;
-      qea_split3(hv[i], h, m, l);
-      const int o = q * CIN + swz(q, c4 >> 1) * 8 + (c4 & 1) * 4;
-      *reinterpret_cast<bf16x4*>(As + o) = h;
-      *reinterpret_cast<bf16x4*>(As + PLANE + o) = m;
-      *reinterpret_cast<bf16x4*>(As + 2 * PLANE + o) = l;
+      const int hx = q % HW_, hy = q / HW_;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = e < HP * C4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)iy * W + ix) * ldx + chunk * CIN + c4 * 4 : x);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      hv[i] = ok ? v : zero;
     }
-  }
-  __syncthreads();
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i;
+      if (e < HP * C4) {
+        const int c4 = e % C4, q = e / C4;
+        bf16x4 h, m, l;
+        qea_split3(hv[i], h, m, l);
+        const int o = q * CIN + swz(q, c4 >> 1) * 8 + (c4 & 1) * 4;
+        *reinterpret_cast<bf16x4*>(As + o) = h;
+        *reinterpret_cast<bf16x4*>(As + PLANE + o) = m;
+        *reinterpret_cast<bf16x4*>(As + 2 * PLANE + o) = l;
+      }
+    }
+  };
 
   const int fr = lane & 31, fh = lane >> 5;
   f32x16 acc[MI];
@@ -1065,41 +1071,49 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // filter fragments: wf[step = tap*KS + cs][plane][nj][lane][8]; this wave's nj = wn
+  // filter fragments: wf[n-block][chunk][step = tap*KS + cs][plane][nj][lane][8]; this wave's nj = wn, n-block = blockIdx.y
   constexpr int STEPS = 9 * KS;
-  const bf16x8* wl = reinterpret_cast<const bf16x8*>(wf) + wn * 64 + lane;
+  const int nb = blockIdx.y;
+  const bf16x8* wl = reinterpret_cast<const bf16x8*>(wf) + (size_t)nb * chunks * STEPS * 3 * WN * 64 + wn * 64 + lane;
   bf16x8 bq[2][3];
-  auto load_b = [&](int st, int buf) {
+  auto load_b = [&](int gst, int buf) {                 // gst = chunk * STEPS + step
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bq[buf][pl] = wl[(size_t)(st * 3 + pl) * WN * 64];
+    for (int pl = 0; pl < 3; ++pl) bq[buf][pl] = wl[(size_t)(gst * 3 + pl) * WN * 64];
   };
+  gather(0);
   load_b(0, 0);
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    if (chunk) __syncthreads();                         // every wave has read the previous chunk's planes
+    stage();
+    __syncthreads();
+    if (chunk + 1 < chunks) gather(chunk + 1);          // in flight under the MFMAs below
 #pragma unroll
-  for (int st = 0; st < STEPS; ++st) {
-    const int cur = st & 1;
-    if (st + 1 < STEPS) load_b(st + 1, cur ^ 1);
-    __builtin_amdgcn_sched_barrier(0);                  // keep the next step's filter loads AHEAD of this step's MFMAs
-    const int tap = st / KS, cs = st % KS;
-    const int kh = tap / 3, kw = tap % 3;
+    for (int st = 0; st < STEPS; ++st) {
+      const int cur = st & 1;                           // STEPS is even for KS = 2, 4: the buffer parity carries over the chunks
+      if (st + 1 < STEPS || chunk + 1 < chunks) load_b(chunk * STEPS + st + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);                // keep the next step's filter loads AHEAD of this step's MFMAs
+      const int tap = st / KS, cs = st % KS;
+      const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int hp = (wm * MI + i + kh) * HW_ + fr + kw;
-      const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + PLANE);
-      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
-      // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[cur][0], acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][2], acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cur][1], acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cur][0], acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][1], acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][0], acc[i], 0, 0, 0);
+      for (int i = 0; i < MI; ++i) {
+        const int hp = (wm * MI + i + kh) * HW_ + fr + kw;
+        const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + PLANE);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
+        // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[cur][0], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][2], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cur][1], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cur][0], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][1], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][0], acc[i], 0, 0, 0);
+      }
     }
   }
 
-  // ---- store: row (= pixel x) = (r&3) + 8*(r>>2) + 4*fh, col (= channel) = wn*32 + fr
-  const int n = wn * 32 + fr;
+  // ---- store: row (= pixel x) = (r&3) + 8*(r>>2) + 4*fh, col (= channel) = nb*COUT + wn*32 + fr
+  const int n = nb * COUT + wn * 32 + fr;
   const float esc = scale ? scale[n] : 1.f, ebi = bias ? bias[n] : 0.f;
   double st0 = 0.0, st1 = 0.0;
 #pragma unroll
@@ -1124,25 +1138,29 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
     const double a = st0 + __shfl_xor(st0, 32, 64);
     const double c = st1 + __shfl_xor(st1, 32, 64);
     if (fh == 0) {
-      double* dst = stats + ((size_t)(blockIdx.x * WM + wm) * COUT + n) * 2;
+      double* dst = stats + ((size_t)(blockIdx.x * WM + wm) * Ntot + n) * 2;
       dst[0] = a;
       dst[1] = c;
     }
   }
 }
 
-// w [N][9][CIN] fp32 (N = 32 or 64 rows) -> fragment-ordered planes [step = tap*KS + cs][plane][nj][lane][8 bf16]:
-// lane (n = nj*32 + (lane & 31), half = lane >> 5) holds channels cs*16 + 8*half + j of filter row n at `tap`
-__global__ void pack_frag_planes_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int N, int CINr) {
-  const int KSr = CINr / 16, WNr = N / 32;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;         // (step, nj, lane)
-  if (i >= 9 * KSr * WNr * 64) return;
+// w [N][9][Cin] fp32 -> fragment-ordered planes [chunk][step = tap*KS + cs][plane][nj][lane][8 bf16], chunk width CW (32 or 64
+// channels), KS = CW / 16: lane (n = nj*32 + (lane & 31), half = lane >> 5) holds channels chunk*CW + cs*16 + 8*half + j of filter
+// row n at `tap`
+__global__ void pack_frag_planes_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int N, int Cin, int CW) {
+  const int NB = N > 128 ? 128 : N;                            // output channels per n-block (one workgroup column)
+  const int KSr = CW / 16, WNr = NB / 32, chunks = Cin / CW;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;         // (n-block, chunk, step, nj, lane)
+  if (i >= (N / NB) * chunks * 9 * KSr * WNr * 64) return;
   const int lane = i & 63;
   const int nj = (i >> 6) % WNr;
-  const int st = (i >> 6) / WNr;
+  const int gst = (i >> 6) / WNr;                              // (n-block, chunk, step) flattened
+  const int nbk = gst / (chunks * 9 * KSr);
+  const int chunk = (gst / (9 * KSr)) % chunks, st = gst % (9 * KSr);
   const int tap = st / KSr, cs = st % KSr;
-  const int n = nj * 32 + (lane & 31);
-  const float* src = w + ((size_t)n * 9 + tap) * CINr + cs * 16 + 8 * (lane >> 5);
+  const int n = nbk * NB + nj * 32 + (lane & 31);
+  const float* src = w + ((size_t)n * 9 + tap) * Cin + chunk * CW + cs * 16 + 8 * (lane >> 5);
   const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
   bf16x4 h0, m0, l0, h1, m1, l1;
   qea_split3(v0, h0, m0, l0);
@@ -1155,7 +1173,7 @@ __global__ void pack_frag_planes_kernel(const float* __restrict__ w, __bf16* __r
     pl[2][k] = l0[k]; pl[2][k + 4] = l1[k];
   }
 #pragma unroll
-  for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + ((((size_t)st * 3 + p) * WNr + nj) * 64 + lane) * 8) = pl[p];
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + ((((size_t)gst * 3 + p) * WNr + nj) * 64 + lane) * 8) = pl[p];
 }
 
 template <int CIN, int COUT, int TH, bool STATS>
@@ -1172,8 +1190,8 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
     qea_set_error("qea_conv_igemm(halo bf3): grid %lld out of range", grid);
     return QEA_ERR_INVALID;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy, a.scale, a.bias,
-                     a.relu, a.stats);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)(a.N / COUT)), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
+                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N);
   return QEA_OK;
 }
 
@@ -1189,15 +1207,28 @@ bool halo_eligible(const qea_conv_desc* d) {
          d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->mask && !d->accumulate;
 }
 
-int launch_halo_bf3_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
-  if (d->Cin == 32 && d->N == 32) return launch_halo_bf3<32, 32, 8>(a, s);
-  if (d->Cin == 32 && d->N == 64) return launch_halo_bf3<32, 64, 8>(a, s);
-  if (d->Cin == 64 && d->N == 32) return launch_halo_bf3<64, 32, 4>(a, s);
-  return launch_halo_bf3<64, 64, 4>(a, s);
+// the split-bf16 LDS-halo kernel takes C_in = 32 or a multiple of 64 (up to 256) and C_out in {32, 64, 128}
+bool halo_bf3_eligible(const qea_conv_desc* d) {
+  const bool cin = d->Cin == 32 || (d->Cin % 64 == 0 && d->Cin <= 512);
+  const bool cout = d->N == 32 || d->N == 64 || d->N % 128 == 0;
+  const int th = d->Cin == 32 ? 8 : 4;
+  return cin && cout && d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H &&
+         d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->mask && !d->accumulate;
 }
 
-// workgroup-rows of the statistics partials: halo fp32 = 4 waves over rows; halo bf3 = WM = 4 / (COUT / 32)
-int halo_bf3_wm(const qea_conv_desc* d) { return 4 / (d->N / 32); }
+int launch_halo_bf3_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  if (d->Cin == 32) {
+    if (d->N == 32) return launch_halo_bf3<32, 32, 8>(a, s);
+    if (d->N == 64) return launch_halo_bf3<32, 64, 8>(a, s);
+    return launch_halo_bf3<32, 128, 8>(a, s);                // (N = 128k: one workgroup column per 128 output channels)
+  }
+  if (d->N == 32) return launch_halo_bf3<64, 32, 4>(a, s);
+  if (d->N == 64) return launch_halo_bf3<64, 64, 4>(a, s);
+  return launch_halo_bf3<64, 128, 4>(a, s);
+}
+
+// workgroup-rows of the statistics partials: halo fp32 = 4 waves over rows; halo bf3 = WM = 4 / (COUT / 32), COUT = min(N, 128)
+int halo_bf3_wm(const qea_conv_desc* d) { return 4 / ((d->N > 128 ? 128 : d->N) / 32); }
 
 int launch_halo_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   if (d->Cin == 32 && d->N == 32) return launch_halo<32, 32, 8>(a, s);
@@ -1205,6 +1236,10 @@ int launch_halo_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   if (d->Cin == 64 && d->N == 32) return launch_halo<64, 32, 4>(a, s);
   return launch_halo<64, 64, 4>(a, s);
 }
+
+// The split-bf16 LDS-halo kernel beats the generic split tiles on EVERY shape it takes (tools/bench_conv.py, B = 512:
+// 32->32 168 vs 95 fp32-halo; 128->64 211 vs 140; 128->128 208 vs 186; 256->256 226 vs 215; 512->512 238 vs 226 TFLOP/s).
+bool halo_bf3_wins(const qea_conv_desc* d) { return halo_bf3_eligible(d); }
 
 // Tile choice for tile == 0 (measured on MI355X with tools/bench_conv.py)
 int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
@@ -1224,7 +1259,8 @@ int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
   const bool bf3 = qea_split_bf16_enabled() && d->N >= 128 && a.K >= 256;
   // 33..64 output channels: the split-bf16 256x64 tile beats both the fp32 256x64 tile (132 vs 107 TFLOP/s at Cin = 128) and
   // the fp32 LDS-halo kernel at Cin = 64 (120 vs 111); the halo kernel keeps Cin = 32 (K = 288: 102 vs 91)
-  if (qea_split_bf16_enabled() && d->N > 32 && d->N <= 64 && a.K >= 256 && d->Cin >= 64) tile = 23;
+  if (qea_split_bf16_enabled() && d->tile != -1 && halo_bf3_wins(d)) tile = 24;   // narrow layers: split-bf16 LDS-halo kernel (168-208 vs 95-120 TFLOP/s)
+  else if (qea_split_bf16_enabled() && d->N > 32 && d->N <= 64 && a.K >= 256 && d->Cin >= 64) tile = 23;
   else if (halo_eligible(d)) tile = 4;
   else if (d->N <= 32) tile = 3;
   else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep; the split-bf16 256x64 tile is slower here)
@@ -1239,13 +1275,25 @@ int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
   return tile;
 }
 
+// the tile a launch runs on: forced, or the automatic choice — which falls back to the fp32 halo / generic split tile when the
+// narrow-layer split kernel was chosen but the caller did not supply the fragment-order filter planes
+int resolve_tile(const qea_conv_desc* d, const ConvArgs& a) {
+  int tile = d->tile ? d->tile : pick_tile(d, a);
+  if (tile == 24 && !d->tile && !d->w_frag_planes) {
+    qea_conv_desc e = *d;
+    e.tile = -1;                                           // the choice without tile 24
+    tile = pick_tile(&e, a);
+  }
+  return tile;
+}
+
 // Partial blocks the fused-statistics epilogue of this launch writes, 0 when the chosen kernel has none: the hybrid
 // split-bf16 tiles (one block per M-tile and wave row) and the fp32 LDS-halo kernel (one per workgroup and wave); the output
 // must be the plain conv result (no scale / bias / ReLU / mask / accumulate, NHWC).
 int stats_blocks_for(const qea_conv_desc* d, const ConvArgs& a, int tile, bool wp3) {
   if (d->scale || d->bias || d->mask || d->relu || d->accumulate || d->out_mode != QEA_OUT_NHWC) return 0;
   if (tile == 4 && halo_eligible(d)) return d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32) * 4;
-  if (tile == 24 && halo_eligible(d)) return d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32) * halo_bf3_wm(d);
+  if (tile == 24 && halo_bf3_eligible(d)) return d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32) * halo_bf3_wm(d);
   if (!wp3) return 0;
   switch (tile) {
     case 21: return qea_cdiv(a.M, 256) * 4;
@@ -1265,7 +1313,7 @@ extern "C" int qea_conv_igemm_stats_blocks(const qea_conv_desc* d) {
   a.M = d->B * d->OH * d->OW;
   a.N = d->N;
   a.K = d->KH * d->KW * d->Cin;
-  const int tile = d->tile ? d->tile : pick_tile(d, a);
+  const int tile = resolve_tile(d, a);
   return stats_blocks_for(d, a, tile, tile >= 20 && !d->x_planes && d->w_planes);
 }
 
@@ -1302,10 +1350,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   a.stats = nullptr;
 
   hipStream_t s = (hipStream_t)stream;
-  int tile = d->tile ? d->tile : pick_tile(d, a);
-  if (tile == 24 && !d->tile && !d->w_frag_planes) {       // auto choice without the fragment-order planes: the previous choices
-    tile = (d->N > 32 && a.K >= 256 && d->Cin >= 64) ? 23 : 4;
-  }
+  int tile = resolve_tile(d, a);
   if (tile == 4 && !halo_eligible(d)) {
     qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate");
     return QEA_ERR_INVALID;
@@ -1330,8 +1375,8 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   switch (tile) {
     case 4: rc = launch_halo_any(d, a, s); break;
     case 24:                                               // split-bf16 LDS-halo kernel of the narrow layers: filter in fragment-order planes
-      if (!halo_eligible(d) || !d->w_frag_planes) {
-        qea_set_error("qea_conv_igemm: tile 24 needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate, and w_frag_planes");
+      if (!halo_bf3_eligible(d) || !d->w_frag_planes) {
+        qea_set_error("qea_conv_igemm: tile 24 needs Cin = 32 or 64k <= 512, N in {32,64,128k}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate, and w_frag_planes");
         return QEA_ERR_INVALID;
       }
       a.wp = (const char*)d->w_frag_planes;
@@ -1389,9 +1434,11 @@ extern "C" int qea_split_planes(const float* x, int32_t ld, int64_t M, int32_t C
 extern "C" size_t qea_pack_frag_planes_bytes(int32_t N, int32_t Cin) { return (size_t)N * 9 * Cin * 6; }
 
 extern "C" int qea_pack_frag_planes(const float* w, int32_t N, int32_t Cin, void* planes, void* stream) {
-  QEA_REQUIRE(w && planes && (N == 32 || N == 64) && (Cin == 32 || Cin == 64), "qea_pack_frag_planes: N and Cin must be 32 or 64");
+  QEA_REQUIRE(w && planes && (N == 32 || N == 64 || (N > 0 && N % 128 == 0)) && (Cin == 32 || (Cin % 64 == 0 && Cin <= 512)),
+              "qea_pack_frag_planes: N in {32, 64, 128k}, Cin = 32 or a multiple of 64 up to 512");
   const int total = 9 * (Cin / 16) * (N / 32) * 64;
-  hipLaunchKernelGGL(pack_frag_planes_kernel, dim3(qea_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)planes, N, Cin);
+  hipLaunchKernelGGL(pack_frag_planes_kernel, dim3(qea_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)planes, N, Cin,
+                     Cin == 32 ? 32 : 64);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

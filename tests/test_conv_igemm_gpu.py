@@ -244,7 +244,8 @@ def test_fused_bn_statistics_epilogue(shape):
 
 
 @pytest.mark.parametrize("Cin,Cout,H,W,B", [(32, 32, 8, 32, 3), (32, 64, 16, 64, 2), (64, 32, 4, 32, 5), (64, 64, 12, 96, 2), (32, 32, 32, 128, 2),
-                                            (64, 64, 16, 64, 3)])
+                                            (64, 64, 16, 64, 3), (128, 64, 16, 64, 2), (64, 128, 8, 32, 3), (128, 128, 8, 32, 2), (256, 128, 4, 32, 3),
+                                            (32, 128, 8, 64, 2), (192, 32, 4, 32, 2), (256, 256, 8, 32, 2), (512, 512, 4, 32, 2), (128, 384, 4, 32, 3)])
 def test_narrow_split_bf16_halo_kernel(Cin, Cout, H, W, B):
     """tile 24 = conv3x3_halo_bf3_kernel (input halo split ONCE into bf16 planes in LDS, filter in fragment-order planes): against
     fp64, against the fp32 LDS-halo kernel (tile 4), reading from / writing into wider (concat) buffers, with the fused
@@ -259,7 +260,8 @@ def test_narrow_split_bf16_halo_kernel(Cin, Cout, H, W, B):
     xb[..., 32:] = x.permute(0, 2, 3, 1).cuda()
     wd = w.permute(0, 2, 3, 1).contiguous().cuda()
     outs = {}
-    for tile in (4, 24):
+    narrow = Cin <= 64 and Cout <= 64
+    for tile in ((4, 24) if narrow else (21, 24)):          # reference kernel: fp32 LDS-halo (narrow) / hybrid split tile
         yb = torch.full((B, H, W, ldy), -3.0, device="cuda")
         got = ops.conv_igemm(xb[..., 32:], wd, yb[..., 64:], B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=ldy,
                              tile=tile, want_stats=True)
@@ -267,13 +269,16 @@ def test_narrow_split_bf16_halo_kernel(Cin, Cout, H, W, B):
         assert (yb[..., :64] == -3.0).all()
         y = yb[..., 64:].cpu().permute(0, 3, 1, 2).double()
         assert (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), tile
-        assert got is not None
+        if got is None:
+            assert tile == 21 and B * H * W < 256                   # (a hybrid tile too large for this M has no statistics blocks)
+            outs[tile] = y
+            continue
         part = got[0].sum(0).cpu()                                   # [Cout][2]
         flat = yb[..., 64:].reshape(-1, Cout).double().cpu()
         assert (part[:, 0] - flat.sum(0)).abs().max().item() <= 1e-9 * flat.abs().sum(0).max().item()
         assert (part[:, 1] - (flat * flat).sum(0)).abs().max().item() <= 1e-9 * (flat * flat).sum(0).max().item()
         outs[tile] = y
-    assert (outs[24] - outs[4]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert (outs[24] - outs[4 if narrow else 21]).abs().max().item() <= 2e-5 * ref.abs().max().item()
     # auto dispatch takes the split kernel; scale + bias + ReLU epilogue
     sc, bi = torch.rand(Cout, generator=g).cuda() + 0.5, torch.randn(Cout, generator=g).cuda()
     y2 = torch.empty(B, H, W, Cout, device="cuda")

@@ -25,6 +25,8 @@ def main():
     shapes = [sh for sh in SHAPES if sh[2] >= 64 and sh[3] >= 64] if len(sys.argv) > 3 and sys.argv[3] == "wide" else SHAPES
     if len(sys.argv) > 3 and sys.argv[3] == "narrow":
         shapes = [sh for sh in SHAPES if sh[2] <= 64 and sh[3] <= 64]
+    if len(sys.argv) > 3 and sys.argv[3] == "mid":
+        shapes = [(16, 64, 128, 64), (16, 64, 64, 128), (8, 32, 64, 128), (8, 32, 128, 128), (8, 32, 256, 128), (16, 64, 128, 128), (4, 32, 256, 128)]
     s = torch.cuda.current_stream().cuda_stream
     tot_t = tot_f = 0.0
     for (H, W, Cin, Cout) in shapes:
@@ -35,7 +37,7 @@ def main():
         wp = torch.empty(L.qea_split_planes_bytes(Cout, 9 * Cin), dtype=torch.uint8, device="cuda")
         _lib.check(L.qea_split_planes(x.data_ptr(), Cin, B * H * W, Cin, xp.data_ptr(), s))
         _lib.check(L.qea_split_planes(w.data_ptr(), 9 * Cin, Cout, 9 * Cin, wp.data_ptr(), s))
-        narrow = Cin in (32, 64) and Cout in (32, 64)
+        narrow = (Cin == 32 or (Cin % 64 == 0 and Cin <= 512)) and (Cout in (32, 64) or Cout % 128 == 0)
         fp = None
         if narrow:
             fp = torch.empty(L.qea_pack_frag_planes_bytes(Cout, Cin), dtype=torch.uint8, device="cuda")
