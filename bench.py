@@ -260,14 +260,19 @@ def main():
         opt_p.step()
         return loss
 
-    def phase_a(w):
-        """train_nn_area.py:214-275.  The black-box OCR itself is outside the path: its labels are the (fixed) ground truth."""
+    def phase_a(w, select_first=False):
+        """train_nn_area.py:214-275.  The black-box OCR itself is outside the path: its labels are the (fixed) ground truth.
+        select_first (--select_before_clean of area_cli, NOT the headline): TopKCER ranks names / CERs only, so the pick can
+        precede the cleaner pass, which then runs on the k picked images instead of the whole minibatch."""
         crnn.train()
         prep.eval()
         prep.zero_grad()
         crnn.zero_grad()
-        with torch.no_grad():
-            preds_all = prep(w.x)
+        if select_first:
+            preds_all = w.x
+        else:
+            with torch.no_grad():
+                preds_all = prep(w.x)
         if world > 1:                                # whole-minibatch ranking over the ranks (32 KB all-gather of the CERs)
             preds, _, idx, kg = w.sampler.query_global(preds_all, w.names, w.k_global, w.names)
             share = world * preds.shape[0] / kg
@@ -275,6 +280,9 @@ def main():
             preds, _, idx = w.sampler.query(preds_all, w.names, w.k_global, w.names)
             share = 1.0
         k = preds.shape[0]
+        if select_first and k:
+            with torch.no_grad():
+                preds = prep(preds.contiguous())
         if k:
             # all replicas in ONE Philox launch and ONE CRNN pass with per-replica-group BatchNorm
             noisy, _ = noiser.batch(preds, replicas=R)
@@ -363,6 +371,16 @@ def main():
             native = (nprof, ndt, nsteps)
         finally:
             ops.set_mfma_mode(prev)
+    sel_first = None
+    if not args.no_secondary and not args.phase_b_only:
+        def step_sf():
+            phase_a(W, select_first=True)
+            return phase_b(W)
+        step_sf()
+        dsf, _ = timed(step_sf, args.steps)
+        sel_first = {"note": "the same full step with area_cli's [new] --select_before_clean: TopKCER picks on names / CERs, the eval-mode "
+                             "cleaner then runs on the k picked images only (same results up to rounding; NOT the reference's order of work)",
+                     "value": B * world * args.steps / dsf, "unit": "patch-images/s", "ms_per_step": dsf / args.steps * 1e3}
     c1 = None
     if not args.no_secondary and B != 512:
         W1 = Work(512)
@@ -454,6 +472,8 @@ def main():
                 "conv_igemm_tflops": tf(nig), "peak": FP32_MFMA_PEAK_TFLOPS, "frac": tf(nig) / FP32_MFMA_PEAK_TFLOPS,
                 "conv_wgrad_tflops": tf(nwg), "conv_wgrad_frac": tf(nwg) / FP32_MFMA_PEAK_TFLOPS,
                 "ms_per_step_single_stream": ndt / nsteps * 1e3, "value": B * world * nsteps / ndt, "steps": nsteps}
+        if sel_first is not None:
+            out["full_step_select_before_clean"] = sel_first
         if c1 is not None:
             out["configs1_b512"] = c1
         if world == 1 and not args.no_cpu_baseline:

@@ -1006,7 +1006,7 @@ template <int CIN, int COUT, int TH, bool STATS>
 __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
-                                                               int Ntot) {
+                                                               int Ntot, const float* __restrict__ mask, int ldmask) {
   constexpr int TW = 32, HW_ = TW + 2, HH = TH + 2, HP = HH * HW_;
   constexpr int WN = COUT / 32, WM = 4 / WN;            // waves across output channels / across tile rows
   constexpr int MI = TH / WM;                           // 32-pixel rows per wave
@@ -1127,6 +1127,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
       else if (scale) v *= esc;
       else if (bias) v += ebi;
       if (relu) v = fmaxf(v, 0.f);
+      if (mask) {                                       // ReLU mask of another tensor (input gradient through a bare ReLU)
+        const size_t mrow = (size_t)(b * H + y0 + wm * MI + i) * W + x0 + px;
+        v = (mask[mrow * ldmask + n] > 0.f) ? v : 0.f;
+      }
       yrow[(size_t)px * ldy + n] = v;
       if (STATS) {
         st0 += (double)v;
@@ -1191,7 +1195,7 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
     return QEA_ERR_INVALID;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)(a.N / COUT)), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
-                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N);
+                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask);
   return QEA_OK;
 }
 
@@ -1213,7 +1217,7 @@ bool halo_bf3_eligible(const qea_conv_desc* d) {
   const bool cout = d->N == 32 || d->N == 64 || d->N % 128 == 0;
   const int th = d->Cin == 32 ? 8 : 4;
   return cin && cout && d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H &&
-         d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->mask && !d->accumulate;
+         d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->accumulate;
 }
 
 int launch_halo_bf3_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {

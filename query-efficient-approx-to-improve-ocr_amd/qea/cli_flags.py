@@ -47,6 +47,9 @@ FLAGS = [
     ("--lr_scheduler", dict(choices=["cosine"], help="Learning-rate scheduler for the CRNN"), "a"),
     # ---- new (additive) ----
     ("--synthetic_size", dict(type=int, help="[new] train on N synthetic samples instead of reading --data_base_path"), "pa"),
+    ("--select_before_clean", dict(action="store_true", help="[new] Phase A: pick the TopKCER / random subset FIRST and run the cleaner only on "
+                                                             "the picked images (the pick depends on names and CERs alone; eval-mode BatchNorm "
+                                                             "makes every image's output independent of the rest of the minibatch)"), "a"),
     ("--per_shard_topk", dict(action="store_true", help="[new] data-parallel runs only: pick the TopKCER subset per GPU shard instead of "
                                                         "over the whole minibatch (not the reference's selection; saves one 32 KB all-gather)"), "a"),
 ]

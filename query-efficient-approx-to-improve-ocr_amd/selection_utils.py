@@ -103,6 +103,8 @@ class TopKCERSampler(DataSampler):
         idx = _desc_stable_topk(_known(names, self.cers), num_samples, images.device if torch.is_tensor(images) else None)
         return self._take(images, labels, idx)
 
+    content_free = True     # the pick depends on names / CERs only: a trainer may pick first and clean only the picked images
+
     def query_global(self, images, labels, num_samples_global, names):
         """Data-parallel form: the reference ranks the WHOLE minibatch (train_nn_area.py:220-225); here the minibatch is sharded
         over the ranks, so the shards' CERs are all-gathered (qea.dist.global_topk: stable descending order, rank-major index

@@ -42,6 +42,7 @@ class TrainNNPrep(TrainerCore):
         tr_idx = torch.randperm(len(train_set))[: self.train_subset_size]
         widths = getattr(train_set, "widths", None)
         self.per_shard_topk = bool(getattr(args, "per_shard_topk", False))
+        self.select_before_clean = bool(getattr(args, "select_before_clean", False))
         if widths is not None:                                # [new] variable-width lines: one width bucket per batch
             # the bucket batches are formed over the WHOLE (rank-identical) list and dealt round-robin, so every rank
             # runs the same number of steps (qea.dist.deal_batches)
@@ -88,8 +89,13 @@ class TrainNNPrep(TrainerCore):
                 X_var = images.to(self.device)
                 # ---------------- Phase A ----------------
                 self._set_phase_a()
-                with torch.no_grad():
-                    img_preds_all = self.prep_model(X_var)
+                select_first = (self.select_before_clean and self.selection_method and epoch >= self.warmup_epochs
+                                and getattr(self.sampler, "content_free", False))
+                if not select_first:
+                    with torch.no_grad():
+                        img_preds_all = self.prep_model(X_var)
+                else:
+                    img_preds_all = X_var                        # [new] pick on the inputs' names, clean only the picked images below
                 share = 1.0                                      # this rank's weight in the data-parallel mean of Phase A
                 if self.selection_method and epoch >= self.warmup_epochs:
                     if self.world > 1 and not self.per_shard_topk and hasattr(self.sampler, "query_global"):
@@ -101,6 +107,9 @@ class TrainNNPrep(TrainerCore):
                     else:
                         k = self._num_bb_samples(img_preds_all.shape[0])
                         img_preds, labels_gt, bb_idx = self.sampler.query(img_preds_all, labels, k, names)
+                    if select_first and img_preds.shape[0]:
+                        with torch.no_grad():                    # eval-mode UNet: each image's output is independent of its batch
+                            img_preds = self.prep_model(img_preds.contiguous())
                     img_preds = img_preds.detach()
                     img_preds_names = [names[i] for i in bb_idx.tolist()]
                     for name in img_preds_names:

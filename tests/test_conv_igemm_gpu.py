@@ -286,3 +286,10 @@ def test_narrow_split_bf16_halo_kernel(Cin, Cout, H, W, B):
                    relu=True)
     want = (ref.permute(0, 2, 3, 1) * sc.cpu().double() + bi.cpu().double()).clamp_min(0)
     assert (y2.cpu().double() - want).abs().max().item() <= 3e-5 * want.abs().max().item()
+    # ReLU-mask epilogue (the input gradient through a bare ReLU: CRNN conv4's dgrad, models/model_crnn.py:50-51)
+    mk = torch.randn(B, H, W, Cout + 32, generator=g).cuda()
+    y3 = torch.empty(B, H, W, Cout, device="cuda")
+    ops.conv_igemm(xb[..., 32:], wd, y3, B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=Cout, mask=mk[..., 32:],
+                   ldmask=Cout + 32)
+    want3 = ref.permute(0, 2, 3, 1) * (mk[..., 32:].cpu() > 0)
+    assert (y3.cpu().double() - want3).abs().max().item() <= 2e-5 * ref.abs().max().item()

@@ -64,6 +64,28 @@ def test_area_trainer_plumbing(tmp_path):
     assert list(crnn.state_dict().keys())
 
 
+def test_area_trainer_select_before_clean_is_the_same_training(tmp_path):
+    """[new] --select_before_clean: TopKCER ranks names / CERs only, so cleaning just the picked images (eval-mode UNet) must
+    train the very same CRNN as cleaning the whole minibatch and then picking (train_nn_area.py:217-225)."""
+    from datasets.synthetic import SyntheticTextAreas
+    from ocr_helper.stub_helper import StubHelper
+    from train_nn_area import TrainNNPrep
+    outs = []
+    for flag in (False, True):
+        tr_set = SyntheticTextAreas(8, seed=1, include_name=True, include_index=True)
+        cers_path = tmp_path / f"cers{int(flag)}.json"
+        json.dump({n: float(i % 5) / 4 + 0.01 * i for i, n in enumerate(tr_set.names)}, open(cers_path, "w"))
+        args = _args("a", tmp_path / f"exp{int(flag)}", batch_size=4, minibatch_subset="topKCER", minibatch_subset_prop=0.5,
+                     cers_ocr_path=str(cers_path), inner_limit=2, select_before_clean=flag)
+        t = TrainNNPrep(args, backend=oracle_backend(), train_set=tr_set, val_set=SyntheticTextAreas(4, seed=2, include_name=True), ocr=StubHelper())
+        t.train()
+        outs.append((torch.cat([p.detach().flatten() for p in t.crnn_model.parameters()]),
+                     torch.cat([p.detach().flatten() for p in t.prep_model.parameters()]),
+                     sorted(n for n, v in t.selected_samples.items() if v[0])))
+    assert outs[0][2] == outs[1][2]
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-4) and torch.allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-4)
+
+
 def test_patch_trainer_plumbing(tmp_path):
     from datasets.synthetic import SyntheticPatches
     from ocr_helper.stub_helper import StubHelper
