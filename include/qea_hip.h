@@ -179,7 +179,10 @@ int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_t C, const 
                        float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
                        float* invstd_out, float* scale_out, float* shift_out, double* stat64, void* workspace,
                        size_t workspace_bytes, void* stream);
-/* the same, from the per-block partial sums a convolution's fused-statistics epilogue wrote (qea_conv_desc.stats) */
+/* the same, from the per-block partial sums a convolution's fused-statistics epilogue wrote (qea_conv_desc.stats).  The
+ * buffer must hold QEA_BN_PARTIAL_SCRATCH_ROWS more rows ([C][2] doubles each) behind the `blocks` partial rows: with many
+ * blocks the reduction runs in two order-fixed stages through them. */
+#define QEA_BN_PARTIAL_SCRATCH_ROWS 256
 int qea_bn_train_stats_from_partials(const double* partials, int32_t blocks, int64_t M, int32_t C, const float* gamma,
                                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                      float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* stat64,

@@ -430,13 +430,63 @@ extern "C" int qea_bn_train_stats(const float* y, int32_t ldy, int64_t M, int32_
   return QEA_OK;
 }
 
+// First stage for MANY partial blocks (the LDS-halo conv kernels leave one per workgroup row: 131072 at B = 2048 on the
+// 32x128 level): workgroup g sums the contiguous block range [g*per, (g+1)*per) for all channels — thread (c2, stripe) walks
+// its stripe of the range with 16-byte loads that are contiguous over the channels, an LDS tree joins the stripes — and writes
+// row g of `out`.  Fixed ranges and a fixed tree: bit-reproducible.  The wave-per-channel finalize kernel then sums <= 256 rows
+// instead of walking thousands of strided loads per lane (250 us -> a few us per BatchNorm layer).
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const double* __restrict__ ws, int nblk, int C, int per, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double sp[];   // [stripes][C][2]
+  const int stripes = 256 / C > 0 ? 256 / C : 1;               // C <= 256 per pass
+  const int b0 = blockIdx.x * per;
+  const int b1 = min(nblk, b0 + per);
+  for (int cbase = 0; cbase < C; cbase += 256) {
+    const int cw = min(256, C - cbase);
+    const int st = cw < 256 ? 256 / cw : 1;
+    const int c = threadIdx.x % cw, stripe = threadIdx.x / cw;
+    double a = 0, b = 0;
+    if (stripe < st) {
+      for (int k = b0 + stripe; k < b1; k += st) {
+        const double* src = ws + ((size_t)k * C + cbase + c) * 2;
+        a += src[0];
+        b += src[1];
+      }
+      sp[((size_t)stripe * cw + c) * 2 + 0] = a;
+      sp[((size_t)stripe * cw + c) * 2 + 1] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < cw) {
+      double t0 = 0, t1 = 0;
+      for (int r = 0; r < st; ++r) {
+        t0 += sp[((size_t)r * cw + threadIdx.x) * 2 + 0];
+        t1 += sp[((size_t)r * cw + threadIdx.x) * 2 + 1];
+      }
+      out[((size_t)blockIdx.x * C + cbase + threadIdx.x) * 2 + 0] = t0;
+      out[((size_t)blockIdx.x * C + cbase + threadIdx.x) * 2 + 1] = t1;
+    }
+    __syncthreads();
+  }
+  (void)stripes;
+}
+
 extern "C" int qea_bn_train_stats_from_partials(const double* partials, int32_t blocks, int64_t M, int32_t C, const float* gamma,
                                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                                 float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* stat64,
                                                 void* stream) {
   QEA_REQUIRE(partials && blocks > 0 && M > 0 && C > 0 && mean_out && invstd_out && scale_out && shift_out,
               "qea_bn_train_stats_from_partials: bad arguments");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, blocks, C, (long long)M,
+  hipStream_t s = (hipStream_t)stream;
+  const double* src = partials;
+  int nblk = blocks;
+  if (blocks > QEA_BN_PARTIAL_SCRATCH_ROWS * 2) {
+    // two stages: QEA_BN_PARTIAL_SCRATCH_ROWS ranges -> the scratch rows the caller left behind the partials
+    const int per = qea_cdiv(blocks, QEA_BN_PARTIAL_SCRATCH_ROWS);
+    nblk = qea_cdiv(blocks, per);
+    double* scratch = const_cast<double*>(partials) + (size_t)blocks * C * 2;
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3(nblk), dim3(256), (size_t)256 * 2 * sizeof(double), s, partials, blocks, C, per, scratch);
+    src = scratch;
+  }
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, src, nblk, C, (long long)M,
                      gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, stat64);
   QEA_CHECK_LAUNCH();
   return QEA_OK;

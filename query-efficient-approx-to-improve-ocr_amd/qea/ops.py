@@ -143,10 +143,10 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
     if want_stats and FUSE_BN_STATS["on"]:
         blocks = L.qea_conv_igemm_stats_blocks(C.byref(d))
         if blocks > 0:
-            partials = torch.empty(blocks, N, 2, dtype=torch.float64, device=x.device)
+            partials = torch.empty(blocks + 256, N, 2, dtype=torch.float64, device=x.device)   # + QEA_BN_PARTIAL_SCRATCH_ROWS
             d.stats = partials.data_ptr()
     _lib.check(L.qea_conv_igemm(C.byref(d), _stream()), "qea_conv_igemm")
-    return (partials, partials.shape[0]) if partials is not None else None
+    return (partials, partials.shape[0] - 256) if partials is not None else None
 
 
 def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride=(1, 1), ldp, ldq,
