@@ -778,30 +778,34 @@ void launch_halo(const qea_wgrad_desc* d, const HaloPlan& h, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 struct Halo9Plan {
   bool ok;
-  int sw, th, tiles_x, tiles_y, n_tiles, r_blks, c_blks, splits;
+  int sw, th, tiles_x, tiles_y, n_tiles, r_blks, c_blks, splits, rb, cb, wk;
 };
 
 constexpr int H9_HP_MAX = 136;   // halo pixels: (2+2) x (32+2) or (4+2) x (16+2) = 108
 
-template <int SW>
+// RB / CB = channel block of dY / X per workgroup (64, or 32 for the 32-channel level): 2x2 waves of 32x32 sub-blocks for
+// 64x64; with fewer sub-blocks the spare waves split the tile's four k-steps (WK = 4 / sub-blocks) and write separate slabs.
+template <int SW, int RB, int CB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ ws, int B, int H, int W, int R, int C,
                             int ldp, int ldq, Halo9Plan hp) {
   constexpr int TH = 64 / SW, HW_ = SW + 2, HH = TH + 2, HP = HH * HW_;
-  constexpr int ROW = 64;                                  // bf16 per LDS pixel row
-  constexpr int P_PLANE = 64 * ROW, Q_PLANE = H9_HP_MAX * ROW;   // elements
+  constexpr int WR = RB / 32, WC = CB / 32, WK = 4 / (WR * WC);
+  constexpr int P_PLANE = 64 * RB, Q_PLANE = H9_HP_MAX * CB;    // bf16 elements per plane
+  constexpr int RC4 = RB / 4, CC4 = CB / 4;                     // float4 chunks per pixel
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* Ps = reinterpret_cast<__bf16*>(smem);            // [3][64 px][64 ch]
-  __bf16* Qs = Ps + 3 * P_PLANE;                            // [3][HP_MAX px][64 ch]
+  __bf16* Ps = reinterpret_cast<__bf16*>(smem);            // [3][64 px][RB ch]
+  __bf16* Qs = Ps + 3 * P_PLANE;                            // [3][HP_MAX px][CB ch]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wk = wave / (WR * WC), wrc = wave % (WR * WC);
+  const int wr = wrc / WC, wc = wrc % WC;
   int bid = blockIdx.x;
   const int c_blk = bid % hp.c_blks;
   bid /= hp.c_blks;
   const int r_blk = bid % hp.r_blks;
   const int split = bid / hp.r_blks;
-  const int r0 = r_blk * 64, c0 = c_blk * 64;
+  const int r0 = r_blk * RB, c0 = c_blk * CB;
 
   f32x16 acc[9];
 #pragma unroll
@@ -809,9 +813,9 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // gather: element e = tid + 256 i -> pixel e / 16, float4 chunk e % 16 (16 chunks = 64 channels)
-  constexpr int NP = 64 * 16 / 256;                         // 4
-  constexpr int NQ = (HP * 16 + 255) / 256;                 // 9 (SW 32) / 7 (SW 16)
+  // gather: element e = tid + 256 i -> pixel e / (channels / 4), float4 chunk e % (channels / 4)
+  constexpr int NP = 64 * RC4 / 256;                        // 4 (RB 64) / 2 (RB 32)
+  constexpr int NQ = (HP * CC4 + 255) / 256;
   f32x4 preg[NP], qreg[NQ];
   auto fetch = [&](int tile) {
     const int tx = tile % hp.tiles_x;
@@ -821,14 +825,14 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int e = tid + 256 * i;
-      const int c4 = e & 15, pix = e >> 4;
+      const int c4 = e % RC4, pix = e / RC4;
       const int py = pix / SW, px = pix - py * SW;
       preg[i] = *reinterpret_cast<const f32x4*>(p + ((size_t)(b * H + y0 + py) * W + x0 + px) * ldp + r0 + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int e = tid + 256 * i;
-      const int c4 = e & 15, hq = e >> 4;
+      const int c4 = e % CC4, hq = e / CC4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (hq < HP) {
         const int hy = hq / HW_, hx = hq - hy * HW_;
@@ -838,14 +842,17 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
       qreg[i] = v;
     }
   };
+  // element offset of float4 chunk c4 of LDS pixel row pix: 64-channel rows swap their two 64-byte chunks by (pix >> 1) & 1;
+  // 32-channel rows are one chunk (four pixel rows of a transposing read already fall on four 64-byte bank ranges)
+  auto row_off = [](int pix, int c4, int chw) { return chw == 64 ? pix * 64 + ((((c4 >> 3) ^ (pix >> 1)) & 1) << 5) + (c4 & 7) * 4 : pix * 32 + c4 * 4; };
   auto stage = [&]() {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int e = tid + 256 * i;
-      const int c4 = e & 15, pix = e >> 4;
+      const int c4 = e % RC4, pix = e / RC4;
       bf16x4 h, m, l;
       qea_split3(preg[i], h, m, l);
-      const int o = pix * ROW + ((((c4 >> 3) ^ (pix >> 1)) & 1) << 5) + (c4 & 7) * 4;
+      const int o = row_off(pix, c4, RB);
       *reinterpret_cast<bf16x4*>(Ps + o) = h;
       *reinterpret_cast<bf16x4*>(Ps + P_PLANE + o) = m;
       *reinterpret_cast<bf16x4*>(Ps + 2 * P_PLANE + o) = l;
@@ -853,11 +860,11 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int e = tid + 256 * i;
-      const int c4 = e & 15, hq = e >> 4;
+      const int c4 = e % CC4, hq = e / CC4;
       if (hq < HP) {
         bf16x4 h, m, l;
         qea_split3(qreg[i], h, m, l);
-        const int o = hq * ROW + ((((c4 >> 3) ^ (hq >> 1)) & 1) << 5) + (c4 & 7) * 4;
+        const int o = row_off(hq, c4, CB);
         *reinterpret_cast<bf16x4*>(Qs + o) = h;
         *reinterpret_cast<bf16x4*>(Qs + Q_PLANE + o) = m;
         *reinterpret_cast<bf16x4*>(Qs + 2 * Q_PLANE + o) = l;
@@ -869,8 +876,11 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
   const int g16 = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
   const int l_pix = (g16 >> 1) * 8 + tq;
   const int l_ch = (g16 & 1) * 16 + tpp * 4;
-  auto frag = [&](const __bf16* plane, int pix, int chunk) {   // pix = LDS pixel row of this lane's first 4-pixel block
-    return tr_frag(plane + pix * ROW + (((chunk ^ (pix >> 1)) & 1) << 5) + l_ch, ROW);   // (pix + 4) >> 1 has the same parity
+  auto frag_p = [&](const __bf16* plane, int pix) {          // pix = LDS pixel row of this lane's first 4-pixel block
+    return RB == 64 ? tr_frag(plane + pix * 64 + (((wr ^ (pix >> 1)) & 1) << 5) + l_ch, 64) : tr_frag(plane + pix * 32 + l_ch, 32);
+  };
+  auto frag_q = [&](const __bf16* plane, int pix) {          // ((pix + 4) >> 1 has the parity of pix >> 1: both reads share the swap)
+    return CB == 64 ? tr_frag(plane + pix * 64 + (((wc ^ (pix >> 1)) & 1) << 5) + l_ch, 64) : tr_frag(plane + pix * 32 + l_ch, 32);
   };
 
   int tile = split;
@@ -881,12 +891,12 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
     __syncthreads();
     if (tile + hp.splits < hp.n_tiles) fetch(tile + hp.splits);   // in flight under the MFMAs below
 #pragma unroll 1
-    for (int ks = 0; ks < 4; ++ks) {                          // k-step = 16 consecutive pixels of one tile row (not unrolled: 144
-                                                              // accumulator + 52 prefetch registers leave no room for hoisted fragments)
+    for (int ks = wk; ks < 4; ks += WK) {                     // k-step = 16 consecutive pixels of one tile row (not unrolled: 144
+                                                              // accumulator + prefetch registers leave no room for hoisted fragments)
       const int py = (ks * 16) / SW, px0 = (ks * 16) % SW;
       bf16x8 af[3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) af[pl] = frag(Ps + pl * P_PLANE, ks * 16 + l_pix, wr);
+      for (int pl = 0; pl < 3; ++pl) af[pl] = frag_p(Ps + pl * P_PLANE, ks * 16 + l_pix);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -894,7 +904,7 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
           const int hq = (py + kh) * HW_ + px0 + kw + l_pix;
           bf16x8 bf[3];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bf[pl] = frag(Qs + pl * Q_PLANE, hq, wc);
+          for (int pl = 0; pl < 3; ++pl) bf[pl] = frag_q(Qs + pl * Q_PLANE, hq);
           f32x16& a9 = acc[kh * 3 + kw];
           // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of wgrad_bf3_kernel
           a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], a9, 0, 0, 0);
@@ -906,8 +916,8 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
         }
     }
   }
-  // this workgroup's 64 x 9 x 64 block of the partial slab of its split: [R][9][C]
-  float* out = ws + (size_t)split * R * 9 * C;
+  // this wave's 32 x 9 x 32 block of the partial slab of (its split, its k-step share): [R][9][C]
+  float* out = ws + ((size_t)split * WK + wk) * R * 9 * C;
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -919,9 +929,9 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
 }
 
 Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
-  Halo9Plan h = {false, 0, 0, 0, 0, 0, 0, 0, 0};
+  Halo9Plan h = {false, 0, 0, 0, 0, 0, 0, 0, 0, 64, 64, 1};
   if (d->KH != 3 || d->KW != 3 || d->pad_h != 1 || d->pad_w != 1 || d->stride_h != 1 || d->stride_w != 1 || d->PH != d->QH || d->PW != d->QW) return h;
-  if (d->R % 64 || d->C % 64) return h;
+  if (d->R % 32 || d->C % 32) return h;
   h.sw = (d->PW % 32 == 0) ? 32 : (d->PW == 16 ? 16 : 0);
   if (!h.sw) return h;
   h.th = 64 / h.sw;
@@ -931,8 +941,11 @@ Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
   const long long nt = (long long)d->B * h.tiles_x * h.tiles_y;
   if (nt > 0x7fffffffLL) return h;
   h.n_tiles = (int)nt;
-  h.r_blks = d->R / 64;
-  h.c_blks = d->C / 64;
+  h.rb = d->R % 64 ? 32 : 64;                                // dY / X channel block per workgroup
+  h.cb = d->C % 64 ? 32 : 64;
+  h.wk = 4 / ((h.rb / 32) * (h.cb / 32));                    // k-step shares (separate slabs)
+  h.r_blks = d->R / h.rb;
+  h.c_blks = d->C / h.cb;
   // two workgroups per CU (77 KB of LDS each): about 512 workgroups, each walking at least 8 tiles
   int splits = d->splits > 0 ? d->splits : 512 / (h.r_blks * h.c_blks);
   if (splits > h.n_tiles / 8) splits = h.n_tiles / 8;
@@ -942,31 +955,34 @@ Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
   return h;
 }
 
-constexpr size_t H9_LDS = (size_t)3 * (64 + H9_HP_MAX) * 64 * 2;   // 76.8 KB
+// the 32- and 64-channel layers are taken by both halo kernels: the split-bf16 nine-tap form wins unless QEA_MFMA=f32
+bool prefer_halo9(const qea_wgrad_desc* d) { return qea_split_bf16_enabled() && halo9_plan(d).ok; }
 
-// 64 x 64 channels is taken by both halo kernels: the split-bf16 nine-tap form wins (measured below) unless QEA_MFMA=f32
-bool prefer_halo9(const qea_wgrad_desc* d) { return qea_split_bf16_enabled() && d->R == 64 && d->C == 64 && halo9_plan(d).ok; }
+template <int SW, int RB, int CB>
+int launch_halo9_(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
+  constexpr size_t lds = (size_t)3 * (64 * RB + H9_HP_MAX * CB) * 2;
+  const long long grid = (long long)h.r_blks * h.c_blks * h.splits;
+  auto kern = wgrad_halo9_bf3_kernel<SW, RB, CB>;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h);
+  return QEA_OK;
+}
 
 int launch_halo9(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
-  const long long grid = (long long)h.r_blks * h.c_blks * h.splits;
   if (h.sw == 32) {
-    auto kern = wgrad_halo9_bf3_kernel<32>;
-    static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H9_LDS);
-    if (attr_rc != (int)hipSuccess) {
-      qea_set_error("qea_conv_wgrad: cannot reserve %zu bytes of LDS: %s", H9_LDS, hipGetErrorString((hipError_t)attr_rc));
-      return QEA_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), H9_LDS, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h);
-  } else {
-    auto kern = wgrad_halo9_bf3_kernel<16>;
-    static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H9_LDS);
-    if (attr_rc != (int)hipSuccess) {
-      qea_set_error("qea_conv_wgrad: cannot reserve %zu bytes of LDS: %s", H9_LDS, hipGetErrorString((hipError_t)attr_rc));
-      return QEA_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), H9_LDS, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h);
+    if (h.rb == 64 && h.cb == 64) return launch_halo9_<32, 64, 64>(d, h, s);
+    if (h.rb == 64) return launch_halo9_<32, 64, 32>(d, h, s);
+    if (h.cb == 64) return launch_halo9_<32, 32, 64>(d, h, s);
+    return launch_halo9_<32, 32, 32>(d, h, s);
   }
-  return QEA_OK;
+  if (h.rb == 64 && h.cb == 64) return launch_halo9_<16, 64, 64>(d, h, s);
+  if (h.rb == 64) return launch_halo9_<16, 64, 32>(d, h, s);
+  if (h.cb == 64) return launch_halo9_<16, 32, 64>(d, h, s);
+  return launch_halo9_<16, 32, 32>(d, h, s);
 }
 
 }  // namespace
@@ -979,7 +995,7 @@ extern "C" size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d) {
   }
   if ((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23) {
     const Halo9Plan h9 = halo9_plan(d);
-    if (h9.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h9.splits);
+    if (h9.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h9.splits * h9.wk);
   }
   const Plan p = make_plan(d);
   if (p.splits <= 1) return 0;
@@ -1015,14 +1031,14 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     const Halo9Plan h9 = halo9_plan(d);
     if (h9.ok) {
       const size_t slab = (size_t)d->R * 9 * d->C;
-      const size_t need9 = slab_workspace_bytes(slab, h9.splits);
+      const size_t need9 = slab_workspace_bytes(slab, h9.splits * h9.wk);
       QEA_REQUIRE(d->workspace && d->workspace_bytes >= need9 && ((uintptr_t)d->workspace & 15) == 0,
                   "qea_conv_wgrad: workspace of %zu bytes required, %zu given", need9, (size_t)d->workspace_bytes);
       hipStream_t hs = (hipStream_t)stream;
       qea_prof_begin(QEA_PROF_CONV_WGRAD, hs);
       rc = launch_halo9(d, h9, hs);
       if (rc != QEA_OK) return rc;
-      reduce_slabs((float*)d->workspace, d->dw, (long long)slab / 4, h9.splits, d->accumulate, hs);
+      reduce_slabs((float*)d->workspace, d->dw, (long long)slab / 4, h9.splits * h9.wk, d->accumulate, hs);
       qea_prof_end(QEA_PROF_CONV_WGRAD, hs, 2.0 * d->B * d->PH * (double)d->PW * (double)slab,
                    4.0 * ((double)d->B * d->PH * d->PW * d->R + (double)d->B * d->QH * d->QW * d->C + (double)slab), true);
       QEA_CHECK_LAUNCH();

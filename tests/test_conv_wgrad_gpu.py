@@ -76,10 +76,11 @@ def test_wgrad_linear():
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 32, 128, 128), (3, 8, 32, 256, 128), (5, 4, 16, 128, 256), (2, 4, 32, 256, 512),
-                                            (2, 16, 64, 64, 128), (1, 4, 32, 512, 512), (9, 4, 16, 256, 256)])
+                                            (2, 16, 64, 64, 128), (1, 4, 32, 512, 512), (9, 4, 16, 256, 256),
+                                            (3, 32, 128, 32, 32), (2, 32, 128, 64, 32), (2, 16, 64, 32, 64), (3, 8, 16, 96, 32), (2, 8, 32, 32, 96)])
 @pytest.mark.parametrize("splits", [0, 1, 3])
 def test_wgrad_nine_tap_split_bf16(B, H, W, Cin, Cout, splits):
-    """tile 23 = wgrad_halo9_bf3_kernel: a workgroup accumulates all nine taps of a 64x64 channel block from ONE staged
+    """tile 23 = wgrad_halo9_bf3_kernel: a workgroup accumulates all nine taps of a 64x64 (or 32-wide) channel block from ONE staged
     dY tile + X halo (split once) instead of gathering and splitting both operands per tap; 32- and 16-pixel-wide tiles,
     image borders, pixel splits (order-fixed slab reduction), accumulate; against torch-CPU autograd in fp64."""
     _conv_case(B, H, W, Cin, Cout, tile=23, splits=splits, seed=B * 100 + H, accumulate=(splits == 3))
