@@ -442,10 +442,11 @@ def main():
             "phase_b": {"value": imgs / dt_b, "unit": "patch-images/s", "ms_per_step": dt_b / args.steps * 1e3,
                         "end_to_end_tflops": FLOP_PER_IMG_FAITHFUL * imgs / dt_b / 1e12 if not args.skip_crnn_wgrad else None,
                         "note": "Phase B alone at the same batch: 9.846 GFLOP per image (SURVEY.md §8d unit of work)"},
-            "roofline": {"bound": "mfma", "kernel": "qea_conv_igemm launches (implicit-GEMM conv fwd/dgrad, convT, LSTM/linear GEMMs): "
-                                                      "conv_igemm_bf3_kernel = fp32 operands split into 3 bf16 planes, six "
-                                                      "v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; conv_igemm_kernel / "
-                                                      "conv3x3_halo_kernel = native v_mfma_f32_32x32x2_f32",
+            "roofline": {"bound": "mfma", "kernel": "qea_conv_igemm launches (implicit-GEMM conv fwd/dgrad, convT, LSTM/linear GEMMs). Split-bf16 "
+                                                      "(fp32 operands as 3 bf16 planes, six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate): "
+                                                      "conv3x3_halo_bf3_kernel (3x3 layers up to 512 channels, W >= 32: halo split once in LDS, "
+                                                      "filter fragments pre-split), conv_igemm_bf3w_kernel (other >= 128-channel GEMMs: pre-split "
+                                                      "filter planes by LDS-DMA); native v_mfma_f32_32x32x2_f32: conv_igemm_kernel / conv3x3_halo_kernel",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "peak_note": f"fp32-equivalent; flop-weighted blend of bf16 dense peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} "
                                       f"({100 * f_split:.0f} % of the class's flops run split-bf16) and the fp32 MFMA peak "

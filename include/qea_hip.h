@@ -252,6 +252,18 @@ int qea_lstm_pack_whh(const float* w_hh, float* packed_fwd, float* packed_bwd, v
 int qea_lstm_layer_fwd(float* gates, float* c, float* y, const float* packed_fwd, int32_t T, int32_t B, void* stream);
 int qea_lstm_layer_bwd(float* gates, const float* c, const float* dy, const float* packed_bwd, float* dc_scratch,
                        int32_t T, int32_t B, void* stream);
+/* ABI v5: the same layer with the recurrent GEMMs in split-bf16 form (three bf16 planes per fp32 value, six
+ * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate: the arithmetic of the split convolution kernels).
+ * qea_lstm_pack_whh_split writes one direction's W_hh as pre-split planes in MFMA-fragment order
+ * (qea_lstm_pack_whh_split_bytes() bytes for each of the forward and backward forms; the two directions' copies
+ * contiguous, as above); h_prev / dgates rows are split on the fly.  The forward step of batches of >= 1 536 rows runs
+ * 128-row workgroups whose weight fragments pass through LDS once per workgroup (LDS-DMA); everything else the 32-row
+ * shape of the fp32 step. */
+size_t qea_lstm_pack_whh_split_bytes(void);
+int qea_lstm_pack_whh_split(const float* w_hh, void* planes_fwd, void* planes_bwd, void* stream);
+int qea_lstm_layer_fwd_split(float* gates, float* c, float* y, const void* planes_fwd, int32_t T, int32_t B, void* stream);
+int qea_lstm_layer_bwd_split(float* gates, const float* c, const float* dy, const void* planes_bwd, float* dc_scratch,
+                             int32_t T, int32_t B, void* stream);
 
 /* log_softmax over the last dim (fn.log_softmax(.., 2), model_crnn.py:20) and its backward
  * dx = g - exp(lp)*sum(g), with the reference's NaN scrub (CRNN.backward_hook,

@@ -116,13 +116,7 @@ class CRNNEngine:
             gates = torch.empty(T, B, 2 * 4 * HID, device=dev)
             whf, whr = P[f"lstm.weight_hh_l{layer}"], P[f"lstm.weight_hh_l{layer}_reverse"]
 
-            def pack(whf=whf, whr=whr):                       # W_hh in per-lane MFMA fragment order, both directions, fwd + bwd forms
-                pf_ = torch.empty(2, 4 * HID * HID, device=dev)
-                pb_ = torch.empty(2, 4 * HID * HID, device=dev)
-                for d_, wh in enumerate((whf, whr)):
-                    ops.lstm_pack_whh(wh, pf_[d_], pb_[d_])
-                return pf_, pb_
-            pf, pb = ops.weight_cached("whh_pack", whf, pack, also=(whr,))
+            pf, pb, split = ops.lstm_packs(whf, whr)               # W_hh in per-lane MFMA fragment order, both directions, fwd + bwd forms
             for d, suf in enumerate(("", "_reverse")):
                 bias = P[f"lstm.bias_ih_l{layer}{suf}"] + P[f"lstm.bias_hh_l{layer}{suf}"]
                 ops.conv_igemm(xin, P[f"lstm.weight_ih_l{layer}{suf}"], gates[:, :, d * 4 * HID:], B=1, H=1, W=T * B, Cin=512, OH=1,
@@ -130,8 +124,8 @@ class CRNNEngine:
                                w_src=("fwd", P[f"lstm.weight_ih_l{layer}{suf}"]))
             cst = torch.empty(T, B, 2 * HID, device=dev)
             y = torch.empty(T, B, 2 * HID, device=dev)
-            ops.lstm_layer_fwd(gates, cst, y, pf, T, B)
-            lstm.append({"x": xin, "gates": gates, "c": cst, "y": y, "pb": pb})
+            ops.lstm_layer_fwd_any(gates, cst, y, pf, split, T, B)
+            lstm.append({"x": xin, "gates": gates, "c": cst, "y": y, "pb": pb, "split": split})
             xin = y
         # Linear + log_softmax (vocab padded to a multiple of 32 columns; pad columns stay 0)
         vp = self.vpad
@@ -196,7 +190,7 @@ class CRNNEngine:
             s = ctx["lstm"][layer]
             gates, cst, yl, xin = s["gates"], s["c"], s["y"], s["x"]
             dc = torch.empty(B, 2 * HID, device=dev)
-            ops.lstm_layer_bwd(gates, cst, dy, s["pb"], dc, T, B)          # gates now hold dgates
+            ops.lstm_layer_bwd_any(gates, cst, dy, s["pb"], s["split"], dc, T, B)          # gates now hold dgates
             if param_grads:
                 def lstm_grads(layer=layer, gates=gates, xin=xin, yl=yl):
                     for d, suf in enumerate(("", "_reverse")):

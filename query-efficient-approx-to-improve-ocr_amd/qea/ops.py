@@ -352,6 +352,48 @@ def lstm_layer_bwd(gates, c, dy, packed_bwd, dc_scratch, T, B):
                                              _stream()), "qea_lstm_layer_bwd")
 
 
+def lstm_pack_whh_split(w_hh, planes_fwd, planes_bwd):
+    _lib.check(_lib.lib().qea_lstm_pack_whh_split(_ptr(w_hh), _ptr(planes_fwd), _ptr(planes_bwd), _stream()), "qea_lstm_pack_whh_split")
+
+
+def lstm_packs(whf, whr):
+    """(fwd pack, bwd pack, split) of one layer's two W_hh for the CURRENT MFMA mode, cached with the weights: three-plane
+    bf16 fragments for the split-bf16 step kernels (default), fp32 fragments for QEA_MFMA=f32."""
+    split = mfma_mode() != "f32"
+    dev = whf.device
+
+    def pack():
+        if split:
+            nb = _lib.lib().qea_lstm_pack_whh_split_bytes()
+            pf_ = torch.empty(2, nb, dtype=torch.uint8, device=dev)
+            pb_ = torch.empty(2, nb, dtype=torch.uint8, device=dev)
+            for d_, wh in enumerate((whf, whr)):
+                lstm_pack_whh_split(wh, pf_[d_], pb_[d_])
+        else:
+            pf_ = torch.empty(2, whf.numel(), device=dev)
+            pb_ = torch.empty(2, whf.numel(), device=dev)
+            for d_, wh in enumerate((whf, whr)):
+                lstm_pack_whh(wh, pf_[d_], pb_[d_])
+        return pf_, pb_
+    pf, pb = weight_cached(("whh_pack", split), whf, pack, also=(whr,))
+    return pf, pb, split
+
+
+def lstm_layer_fwd_any(gates, c, y, pack, split, T, B):
+    if split:
+        _lib.check(_lib.lib().qea_lstm_layer_fwd_split(_ptr(gates), _ptr(c), _ptr(y), _ptr(pack), T, B, _stream()), "qea_lstm_layer_fwd_split")
+    else:
+        lstm_layer_fwd(gates, c, y, pack, T, B)
+
+
+def lstm_layer_bwd_any(gates, c, dy, pack, split, dc_scratch, T, B):
+    if split:
+        _lib.check(_lib.lib().qea_lstm_layer_bwd_split(_ptr(gates), _ptr(c), _ptr(dy), _ptr(pack), _ptr(dc_scratch), T, B, _stream()),
+                   "qea_lstm_layer_bwd_split")
+    else:
+        lstm_layer_bwd(gates, c, dy, pack, dc_scratch, T, B)
+
+
 def log_softmax_fwd(x, ldx, y, ldy, M, C_):
     _lib.check(_lib.lib().qea_log_softmax_fwd(_ptr(x), ldx, _ptr(y), ldy, M, C_, _stream()), "qea_log_softmax_fwd")
 

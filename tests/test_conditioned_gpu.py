@@ -83,7 +83,7 @@ def test_qualified_candidates_within_1e4(case, mfma_mode):
 
 
 def test_all_candidates_statistics():
-    """The same comparison over EVERY candidate (16) in both modes, stated so that it does not depend on which candidates
+    """The same comparison over EVERY candidate (20) in both modes, stated so that it does not depend on which candidates
     happen to be flip-free for this build (a ReLU / max-pool decision taken the other way moves the gradients UPSTREAM of it
     by 1e-3..1e-2 and nothing else — DESIGN.md §4):
       * always: losses within 1e-4, forward activations within 1e-5 / 1e-4, BN statistics within 1e-5, no tensor off by more

@@ -242,8 +242,11 @@ def test_head_fwd_bwd():
 
 
 # ----------------------------------------------------------------------------- LSTM
-@pytest.mark.parametrize("T,B", [(31, 5), (7, 70)])
-def test_lstm_layer_fwd_bwd(T, B):
+@pytest.mark.parametrize("T,B,step", [(31, 5, "f32"), (7, 70, "f32"), (31, 5, "split"), (7, 70, "split"), (3, 1571, "split"), (4, 2048, "split"),
+                                      (3, 1571, "f32")])
+def test_lstm_layer_fwd_bwd(T, B, step):
+    """step = "f32": lstm_step_kernel (v_mfma_f32_32x32x2_f32); "split": lstm_step_bf3_kernel (split-bf16 recurrent GEMMs; 32-row
+    workgroups below 1 536 rows, 128-row workgroups with LDS-DMA weight stages above, ragged last row block included)."""
     from oracle import model_oracle as mo
     from qea import ops
     g = torch.Generator().manual_seed(T * 100 + B)
@@ -267,15 +270,22 @@ def test_lstm_layer_fwd_bwd(T, B):
         bias = (P["b_ih" + s] + P["b_hh" + s]).detach().to(dev)
         ops.conv_igemm(xd, P["w_ih" + s].detach().to(dev), gates[:, :, d * 1024:], B=1, H=1, W=T * B, Cin=In, OH=1, OW=T * B,
                        N=1024, KH=1, KW=1, ldx=In, ldy=2048, bias=bias)
-    pf, pb = torch.empty(2, 1024 * 256, device=dev), torch.empty(2, 1024 * 256, device=dev)
+    split = step == "split"
+    if split:
+        from qea import _lib
+        nb = _lib.lib().qea_lstm_pack_whh_split_bytes()
+        assert nb == 1024 * 256 * 3 * 2
+        pf, pb = torch.empty(2, nb, dtype=torch.uint8, device=dev), torch.empty(2, nb, dtype=torch.uint8, device=dev)
+    else:
+        pf, pb = torch.empty(2, 1024 * 256, device=dev), torch.empty(2, 1024 * 256, device=dev)
     for d, s in enumerate(("", "_reverse")):
-        ops.lstm_pack_whh(P["w_hh" + s].detach().to(dev), pf[d], pb[d])
+        (ops.lstm_pack_whh_split if split else ops.lstm_pack_whh)(P["w_hh" + s].detach().to(dev), pf[d], pb[d])
     c, y = torch.empty(T, B, 512, device=dev), torch.empty(T, B, 512, device=dev)
-    ops.lstm_layer_fwd(gates, c, y, pf, T, B)
+    ops.lstm_layer_fwd_any(gates, c, y, pf, split, T, B)
     torch.cuda.synchronize()
     assert rel_err(y.cpu(), out.detach()) < 2e-5
     dc = torch.empty(B, 512, device=dev)
-    ops.lstm_layer_bwd(gates, c, dy.to(dev), pb, dc, T, B)
+    ops.lstm_layer_bwd_any(gates, c, dy.to(dev), pb, split, dc, T, B)
     torch.cuda.synchronize()
     # dgates -> dW_ih, db, dX via the generic kernels
     for d, s in enumerate(("", "_reverse")):
