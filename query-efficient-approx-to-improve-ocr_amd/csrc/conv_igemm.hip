@@ -1020,7 +1020,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_x = W / TW, tiles_y = H / TH;
-  int bid = blockIdx.x;
+  // 1-D grid of (pixel tile, 128-channel group): the groups of one tile read the same input halo — consecutive slots of one
+  // XCD (swizzle), so the halo is fetched from HBM once instead of once per group
+  const int nblk = Ntot / COUT;
+  const int lid = qea_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int nb = lid % nblk;
+  const int tile_id = lid / nblk;
+  int bid = tile_id;
   const int tx = bid % tiles_x;
   bid /= tiles_x;
   const int ty = bid % tiles_y;
@@ -1071,9 +1077,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // filter fragments: wf[n-block][chunk][step = tap*KS + cs][plane][nj][lane][8]; this wave's nj = wn, n-block = blockIdx.y
+  // filter fragments: wf[n-block][chunk][step = tap*KS + cs][plane][nj][lane][8]; this wave's nj = wn
   constexpr int STEPS = 9 * KS;
-  const int nb = blockIdx.y;
   const bf16x8* wl = reinterpret_cast<const bf16x8*>(wf) + (size_t)nb * chunks * STEPS * 3 * WN * 64 + wn * 64 + lane;
   bf16x8 bq[2][3];
   auto load_b = [&](int gst, int buf) {                 // gst = chunk * STEPS + step
@@ -1142,7 +1147,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
     const double a = st0 + __shfl_xor(st0, 32, 64);
     const double c = st1 + __shfl_xor(st1, 32, 64);
     if (fh == 0) {
-      double* dst = stats + ((size_t)(blockIdx.x * WM + wm) * Ntot + n) * 2;
+      double* dst = stats + ((size_t)(tile_id * WM + wm) * Ntot + n) * 2;
       dst[0] = a;
       dst[1] = c;
     }
@@ -1189,12 +1194,12 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
     qea_set_error("qea_conv_igemm(halo bf3): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
     return QEA_ERR_LAUNCH;
   }
-  const long long grid = (long long)a.B * (a.H / TH) * (a.W / 32);
+  const long long grid = (long long)a.B * (a.H / TH) * (a.W / 32) * (a.N / COUT);
   if (grid <= 0 || grid > 0x7fffffffLL) {
     qea_set_error("qea_conv_igemm(halo bf3): grid %lld out of range", grid);
     return QEA_ERR_INVALID;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)(a.N / COUT)), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
                      a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask);
   return QEA_OK;
 }

@@ -800,7 +800,9 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WR * WC), wrc = wave % (WR * WC);
   const int wr = wrc / WC, wc = wrc % WC;
-  int bid = blockIdx.x;
+  // the r_blks x c_blks workgroups of one split walk the SAME pixel tiles: the XCD swizzle gives them consecutive slots of one
+  // XCD, so the tiles come out of that XCD's L2 instead of being fetched by all eight (PMC: 2.1 GB -> see DESIGN.md per launch)
+  int bid = qea_xcd_swizzle(blockIdx.x, gridDim.x);
   const int c_blk = bid % hp.c_blks;
   bid /= hp.c_blks;
   const int r_blk = bid % hp.r_blks;
