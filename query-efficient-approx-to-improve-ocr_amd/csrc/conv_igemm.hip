@@ -1003,10 +1003,10 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
 // CIN is the channel CHUNK held in LDS at a time (32, or 64 for every wider input: `chunks` = C_in / 64 passes over the same
 // pixel tile, the next chunk's halo gathered into registers under this chunk's MFMAs); COUT in {32, 64, 128}.
 template <int CIN, int COUT, int TH, bool STATS>
-__global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
-                                                               int Ntot, const float* __restrict__ mask, int ldmask) {
+                                                               int Ntot, const float* __restrict__ mask, int ldmask, int total) {
   constexpr int TW = 32, HW_ = TW + 2, HH = TH + 2, HP = HH * HW_;
   constexpr int WN = COUT / 32, WM = 4 / WN;            // waves across output channels / across tile rows
   constexpr int MI = TH / WM;                           // 32-pixel rows per wave
@@ -1017,21 +1017,28 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* As = reinterpret_cast<__bf16*>(smem);         // [3][HP][CIN]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
   const int tiles_x = W / TW, tiles_y = H / TH;
-  // 1-D grid of (pixel tile, 128-channel group): the groups of one tile read the same input halo — consecutive slots of one
-  // XCD (swizzle), so the halo is fetched from HBM once instead of once per group
+  // Work item = (pixel tile, 128-channel group), `total` of them.  The groups of one tile read the same input halo and get
+  // consecutive slots of one XCD (swizzle).  The grid is PERSISTENT (at most two workgroups per CU, what the LDS allows):
+  // a workgroup walks items blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 or == total, so all its items stay on
+  // its XCD's contiguous range) and gathers the NEXT item's first halo chunk into registers under the current item's last
+  // MFMA phase — the 2-4 us of HBM latency at the head of every tile were 30-40 % of a narrow layer's tile time.
   const int nblk = Ntot / COUT;
-  const int lid = qea_xcd_swizzle(blockIdx.x, gridDim.x);
-  const int nb = lid % nblk;
-  const int tile_id = lid / nblk;
-  int bid = tile_id;
-  const int tx = bid % tiles_x;
-  bid /= tiles_x;
-  const int ty = bid % tiles_y;
-  const int b = bid / tiles_y;
-  const int x0 = tx * TW, y0 = ty * TH;
+  struct Item { int nb, tile_id, b, x0, y0; };
+  auto decode = [&](int vb) {
+    const int lid = qea_xcd_swizzle(vb, total);
+    Item it;
+    it.nb = lid % nblk;
+    it.tile_id = lid / nblk;
+    int bid = it.tile_id;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    it.b = bid / tiles_y;
+    it.x0 = tx * TW;
+    it.y0 = ty * TH;
+    return it;
+  };
 
   // slot swizzle: 64-byte rows (CIN 32) put 4 pixels in a bank row -> key (p >> 2) & 3; 128-byte rows (CIN 64): 2 pixels -> (p >> 1) & 7
   auto swz = [](int p, int slot) { return SLOTS == 4 ? (slot ^ ((p >> 2) & 3)) : (slot ^ ((p >> 1) & 7)); };
@@ -1039,27 +1046,35 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
   // ---- halo of one channel chunk: gather (zero outside the image), split once, three planes into LDS
   constexpr int C4 = CIN / 4;
   constexpr int NLD = (HP * C4 + 255) / 256;
-  const float* xb = x + (size_t)b * H * W * ldx;
   f32x4 hv[NLD];
-  auto gather = [&](int chunk) {
+  // element e = tid + 256 i of the halo: float4 chunk c4 = e % C4 (the same for every i: 256 % C4 == 0), pixel q = e / C4 walks
+  // in steps of 256 / C4 (< 34), so (hx, hy) advance without divisions
+  constexpr int QS = 256 / C4;
+  auto gather = [&](const Item& it, int chunk, int tid) {
+    const float* xb = x + (size_t)it.b * H * W * ldx + chunk * CIN + (tid % C4) * 4;
+    int q = tid / C4;
+    int hy = q / HW_, hx = q - hy * HW_;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int e = tid + 256 * i;
-      const int c4 = e % C4, q = e / C4;
-      const int hx = q % HW_, hy = q / HW_;
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      const bool ok = e < HP * C4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)iy * W + ix) * ldx + chunk * CIN + c4 * 4 : x);
+      const int iy = it.y0 + hy - 1, ix = it.x0 + hx - 1;
+      const bool ok = q < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)iy * W + ix) * ldx : x);
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       hv[i] = ok ? v : zero;
+      q += QS;
+      hx += QS;
+      if (hx >= HW_) {
+        hx -= HW_;
+        ++hy;
+      }
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int tid) {
+    const int c4 = tid % C4;
+    int q = tid / C4;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int e = tid + 256 * i;
-      if (e < HP * C4) {
-        const int c4 = e % C4, q = e / C4;
+      if (q < HP) {
         bf16x4 h, m, l;
         qea_split3(hv[i], h, m, l);
         const int o = q * CIN + swz(q, c4 >> 1) * 8 + (c4 & 1) * 4;
@@ -1067,90 +1082,119 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf3_kernel(const float* __re
         *reinterpret_cast<bf16x4*>(As + PLANE + o) = m;
         *reinterpret_cast<bf16x4*>(As + 2 * PLANE + o) = l;
       }
+      q += QS;
     }
   };
-
-  const int fr = lane & 31, fh = lane >> 5;
-  f32x16 acc[MI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   // filter fragments: wf[n-block][chunk][step = tap*KS + cs][plane][nj][lane][8]; this wave's nj = wn
   constexpr int STEPS = 9 * KS;
-  const bf16x8* wl = reinterpret_cast<const bf16x8*>(wf) + (size_t)nb * chunks * STEPS * 3 * WN * 64 + wn * 64 + lane;
   bf16x8 bq[2][3];
-  auto load_b = [&](int gst, int buf) {                 // gst = chunk * STEPS + step
+  auto load_b = [&](int nb, int gst, int buf, int tid) {   // gst = chunk * STEPS + step
+    const bf16x8* wl = reinterpret_cast<const bf16x8*>(wf) + ((tid >> 6) % WN) * 64 + (tid & 63) + (size_t)nb * chunks * STEPS * 3 * WN * 64;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) bq[buf][pl] = wl[(size_t)(gst * 3 + pl) * WN * 64];
   };
-  gather(0);
-  load_b(0, 0);
-  for (int chunk = 0; chunk < chunks; ++chunk) {
-    if (chunk) __syncthreads();                         // every wave has read the previous chunk's planes
-    stage();
-    __syncthreads();
-    if (chunk + 1 < chunks) gather(chunk + 1);          // in flight under the MFMAs below
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-      const int cur = st & 1;                           // STEPS is even for KS = 2, 4: the buffer parity carries over the chunks
-      if (st + 1 < STEPS || chunk + 1 < chunks) load_b(chunk * STEPS + st + 1, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);                // keep the next step's filter loads AHEAD of this step's MFMAs
-      const int tap = st / KS, cs = st % KS;
-      const int kh = tap / 3, kw = tap % 3;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int hp = (wm * MI + i + kh) * HW_ + fr + kw;
-        const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + PLANE);
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
-        // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[cur][0], acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][2], acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cur][1], acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cur][0], acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][1], acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cur][0], acc[i], 0, 0, 0);
-      }
-    }
-  }
 
-  // ---- store: row (= pixel x) = (r&3) + 8*(r>>2) + 4*fh, col (= channel) = nb*COUT + wn*32 + fr
-  const int n = nb * COUT + wn * 32 + fr;
-  const float esc = scale ? scale[n] : 1.f, ebi = bias ? bias[n] : 0.f;
-  double st0 = 0.0, st1 = 0.0;
+  int vb = blockIdx.x;
+  Item cur = decode(vb);
+  gather(cur, 0, threadIdx.x);
+  load_b(cur.nb, 0, 0, threadIdx.x);
+  bool first = true;
+  while (true) {
+    const int nvb = vb + gridDim.x;
+    const bool has_next = nvb < total;
+    const Item nxt = decode(has_next ? nvb : vb);
+    f32x16 acc[MI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    float* yrow = y + ((size_t)(b * H + y0 + wm * MI + i) * W + x0) * ldy;
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
-      float v = acc[i][r];
-      if (scale && bias) v = __fmaf_rn(v, esc, ebi);
-      else if (scale) v *= esc;
-      else if (bias) v += ebi;
-      if (relu) v = fmaxf(v, 0.f);
-      if (mask) {                                       // ReLU mask of another tensor (input gradient through a bare ReLU)
-        const size_t mrow = (size_t)(b * H + y0 + wm * MI + i) * W + x0 + px;
-        v = (mask[mrow * ldmask + n] > 0.f) ? v : 0.f;
-      }
-      yrow[(size_t)px * ldy + n] = v;
-      if (STATS) {
-        st0 += (double)v;
-        st1 += (double)v * (double)v;
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+      // the thread id as an opaque value per chunk: every gather / staging / fragment address below is a function of it, i.e.
+      // invariant over the chunk and item loops (the XOR swizzle makes each of the 36 x MI fragment addresses its own
+      // register) — hoisted they cost > 100 live registers (the one-item kernel needed 278 = ONE workgroup per CU);
+      // recomputed per chunk they are ~700 VALU ops against 860 MFMAs per wave
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, wave = tid >> 6;
+      const int wm = wave / WN;
+      const int fr = lane & 31, fh = lane >> 5;
+      if (!first) __syncthreads();                      // every wave has read the previous planes
+      first = false;
+      stage(tid);
+      __syncthreads();
+      if (chunk + 1 < chunks) gather(cur, chunk + 1, tid);   // in flight under the MFMAs below
+      else if (has_next) gather(nxt, 0, tid);                // ... or the next item's first chunk
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int cb = st & 1;                          // STEPS is even for KS = 2, 4: the buffer parity carries over chunks and items
+        if (st + 1 < STEPS || chunk + 1 < chunks) load_b(cur.nb, chunk * STEPS + st + 1, cb ^ 1, tid);
+        else if (has_next) load_b(nxt.nb, 0, cb ^ 1, tid);
+        __builtin_amdgcn_sched_barrier(0);              // keep the next step's filter loads AHEAD of this step's MFMAs
+        const int tap = st / KS, cs = st % KS;
+        const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int hp = (wm * MI + i + kh) * HW_ + fr + kw;
+          const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + PLANE);
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
+          // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[cb][0], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cb][2], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cb][1], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cb][0], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cb][1], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cb][0], acc[i], 0, 0, 0);
+        }
       }
     }
-  }
-  if (STATS) {                                          // one partial per (workgroup, wave row): [blocks][COUT][2]
-    const double a = st0 + __shfl_xor(st0, 32, 64);
-    const double c = st1 + __shfl_xor(st1, 32, 64);
-    if (fh == 0) {
-      double* dst = stats + ((size_t)(tile_id * WM + wm) * Ntot + n) * 2;
-      dst[0] = a;
-      dst[1] = c;
+
+    // ---- store: row (= pixel x) = (r&3) + 8*(r>>2) + 4*fh, col (= channel) = nb*COUT + wn*32 + fr
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int n = cur.nb * COUT + wn * 32 + fr;
+    const float esc = scale ? scale[n] : 1.f, ebi = bias ? bias[n] : 0.f;
+    double st0 = 0.0, st1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float* yrow = y + ((size_t)(cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0) * ldy;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        float v = acc[i][r];
+        if (scale && bias) v = __fmaf_rn(v, esc, ebi);
+        else if (scale) v *= esc;
+        else if (bias) v += ebi;
+        if (relu) v = fmaxf(v, 0.f);
+        if (mask) {                                     // ReLU mask of another tensor (input gradient through a bare ReLU)
+          const size_t mrow = (size_t)(cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0 + px;
+          v = (mask[mrow * ldmask + n] > 0.f) ? v : 0.f;
+        }
+        yrow[(size_t)px * ldy + n] = v;
+        if (STATS) {
+          st0 += (double)v;
+          st1 += (double)v * (double)v;
+        }
+      }
     }
+    if (STATS) {                                        // one partial per (pixel tile, wave row): [blocks][Ntot][2]
+      const double sa = st0 + __shfl_xor(st0, 32, 64);
+      const double sc = st1 + __shfl_xor(st1, 32, 64);
+      if (fh == 0) {
+        double* dst = stats + ((size_t)(cur.tile_id * WM + wm) * Ntot + n) * 2;
+        dst[0] = sa;
+        dst[1] = sc;
+      }
+    }
+    if (!has_next) break;
+    cur = nxt;
+    vb = nvb;
   }
 }
 
@@ -1194,13 +1238,23 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
     qea_set_error("qea_conv_igemm(halo bf3): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
     return QEA_ERR_LAUNCH;
   }
-  const long long grid = (long long)a.B * (a.H / TH) * (a.W / 32) * (a.N / COUT);
-  if (grid <= 0 || grid > 0x7fffffffLL) {
-    qea_set_error("qea_conv_igemm(halo bf3): grid %lld out of range", grid);
+  const long long total = (long long)a.B * (a.H / TH) * (a.W / 32) * (a.N / COUT);
+  if (total <= 0 || total > 0x7fffffffLL) {
+    qea_set_error("qea_conv_igemm(halo bf3): grid %lld out of range", total);
     return QEA_ERR_INVALID;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
-                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask);
+  // persistent: two workgroups per CU (the LDS bound) once there are more items than that
+  static const int resident = [] {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 2 * (cus & ~7);
+  }();
+  // (32-channel outputs keep one item per workgroup: two persistent workgroups of a CU fall into lockstep there — both staging,
+  // then both in their MFMA phase — and lose the overlap that staggered dispatch gives: 150-159 vs 159-166 TFLOP/s measured)
+  const unsigned grid = (total > resident && COUT > 32) ? (unsigned)resident : (unsigned)total;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
+                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total);
   return QEA_OK;
 }
 
