@@ -286,7 +286,7 @@ def main():
         if k:
             # all replicas in ONE Philox launch and ONE CRNN pass with per-replica-group BatchNorm
             noisy, _ = noiser.batch(preds, replicas=R)
-            lpA = crnn(noisy, replica_groups=R)
+            lpA = crnn(noisy, replica_groups=R, backward_group=R - 1)   # as train_nn_area does: the last replica's samples only
             sel = idx.tolist()
             yA = torch.cat([w.y[int(w.off[i]):int(w.off[i + 1])] for i in sel])
             lossA = ctc(lpA[:, (R - 1) * k:, :], yA, torch.full((k,), 31, dtype=torch.int32), w.lens[idx.cpu()])

@@ -75,10 +75,13 @@ class CRNN(nn.Module):
             raise QeaError("CRNN: batchnorm1/batchnorm2 must be in the same mode")
         return modes.pop()
 
-    def forward(self, x, replica_groups=1):
+    def forward(self, x, replica_groups=1, backward_group=None):
         """x [B,1,32,W] -> log-probs [T,B,vocab].  replica_groups = R (new, additive): x holds R jitter replicas
         of the same strips stacked replica-major; batch-stat BatchNorm runs per replica group, so one call equals R
-        sequential calls of the reference on the R replicas (see CRNNEngine.forward)."""
+        sequential calls of the reference on the R replicas (see CRNNEngine.forward).
+        backward_group = g (new, additive): only replica group g will be back-propagated (the area flow keeps the last
+        replica's loss only, train_nn_area.py:269-271).  The other groups' log-probs are returned DETACHED, so no gradient
+        can reach them, and the backward pass runs on that group's B/R samples instead of on all B."""
         _require_cuda(x, "CRNN")
         eng = self._engine()
         ensure_flat(self)
@@ -88,8 +91,15 @@ class CRNN(nn.Module):
             self.__dict__["_qea_anchor"] = anchor
         wants = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         skip = self.__dict__.get("_qea_skip_param_grads", False)
-        return CRNNFn.apply(x, anchor if wants else None, eng, self._bn_mode(), bool(self.__dict__.get("_qea_nan_scrub", False)), not skip,
-                            int(replica_groups))
+        R = int(replica_groups)
+        g = -1 if backward_group is None or R <= 1 else int(backward_group)
+        if g >= R:
+            raise ValueError(f"backward_group {g} out of range for {R} replica groups")
+        out = CRNNFn.apply(x, anchor if wants else None, eng, self._bn_mode(), bool(self.__dict__.get("_qea_nan_scrub", False)), not skip, R, g)
+        if g >= 0 and out.requires_grad:
+            k = x.shape[0] // R
+            out = torch.cat([out[:, :g * k].detach(), out[:, g * k:(g + 1) * k], out[:, (g + 1) * k:].detach()], dim=1)
+        return out
 
     def map_to_sequence(self, map):
         batch, channel, height, width = map.size()

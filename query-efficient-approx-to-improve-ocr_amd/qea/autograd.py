@@ -33,9 +33,11 @@ class UNetFn(torch.autograd.Function):
 
 class CRNNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, engine, bn_training, nan_scrub, param_grads, groups=1):
+    def forward(ctx, x, anchor, engine, bn_training, nan_scrub, param_grads, groups=1, grad_group=-1):
         need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         out, saved = engine.forward(x.contiguous(), bn_training, need_grad=need, groups=groups)
+        if saved is not None:
+            saved["grad_group"] = int(grad_group)
         ctx.engine, ctx.saved, ctx.nan_scrub, ctx.param_grads = engine, saved, nan_scrub, param_grads
         ctx.need_dx = bool(ctx.needs_input_grad[0])
         return out
@@ -46,7 +48,7 @@ class CRNNFn(torch.autograd.Function):
             raise QeaError("CRNN backward called without saved activations")
         dx = ctx.engine.backward(ctx.saved, dlp, ctx.nan_scrub, ctx.need_dx, ctx.param_grads)
         ctx.saved = None
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class CTCFn(torch.autograd.Function):

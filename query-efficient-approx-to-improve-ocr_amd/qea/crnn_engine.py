@@ -147,6 +147,12 @@ class CRNNEngine:
         P = dict(self.m.named_parameters())
         G = {n: p.grad for n, p in P.items()}
         dev = dlp.device
+        full = None
+        if ctx.get("grad_group", -1) >= 0 and ctx["groups"] > 1:
+            # only ONE replica group receives a gradient (CRNN.forward(backward_group=g) detached the others): run the whole
+            # backward on that group's samples.  Batch-major activations are row slices; the [T][B][..] sequence buffers are copied.
+            full = (ctx["B"], ctx["x"])
+            ctx, dlp = self._group_slice(ctx, dlp)
         B, H, W, T = ctx["B"], ctx["H"], ctx["W"], ctx["T"]
         acts, dims = ctx["acts"], ctx["dims"]
         vp, V = self.vpad, self.vocab
@@ -307,4 +313,35 @@ class CRNNEngine:
             dx = torch.empty(B, 1, H, W, device=dev)
             ops.conv_c1_dgrad(dy1, 64, P[c + "conv1.weight"], dx, B, H, W, 64)
         side.join()
+        if full is not None and dx is not None:
+            Bf, g, k = full[0], ctx["_g"], B
+            dxf = torch.zeros(Bf, 1, H, W, device=dev)
+            dxf[g * k:(g + 1) * k].copy_(dx)
+            dx = dxf
         return dx
+
+    @staticmethod
+    def _group_slice(ctx, dlp):
+        """The saved context and the output gradient restricted to replica group g = ctx["grad_group"]."""
+        g, R, B = ctx["grad_group"], ctx["groups"], ctx["B"]
+        k = B // R
+        b0 = g * k
+        T = ctx["T"]
+        dims = ctx["dims"]
+        sub = dict(ctx)
+        sub.update(B=k, groups=1, grad_group=-1, _g=g, x=ctx["x"][b0:b0 + k])
+        acts = {}
+        for name, t in ctx["acts"].items():
+            if t is None:
+                acts[name] = None
+            elif name.startswith("coef") or name.startswith("st"):
+                acts[name] = t[g:g + 1] if t.shape[0] == R else t        # per-group BN coefficients / fp64 statistics
+            else:
+                rows = t.shape[0] // B                                   # pixels per sample at this layer
+                acts[name] = t[b0 * rows:(b0 + k) * rows]
+        sub["acts"] = acts
+        sub["lstm"] = [{key: (v[:, b0:b0 + k].contiguous() if torch.is_tensor(v) and v.dim() == 3 and v.shape[:2] == (T, B) else v)
+                        for key, v in s.items()} for s in ctx["lstm"]]
+        lp = ctx["lp"]
+        sub["lp"] = lp.view(T, B, -1)[:, b0:b0 + k].contiguous().view(T * k, -1)
+        return sub, dlp[:, b0:b0 + k].contiguous()

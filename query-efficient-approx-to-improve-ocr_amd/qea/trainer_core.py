@@ -159,7 +159,7 @@ class TrainerCore:
         res = [noiser(img) for img in imgs]
         return torch.stack([r[0] if isinstance(r, tuple) else r for r in res])
 
-    def _replica_losses(self, imgs, noiser, R):
+    def _replica_losses(self, imgs, noiser, R, last_only=False):
         """The R jittered CRNN passes of Phase A (train_nn_patch.py:288-294 repeated R times).
         HIP path: ONE Philox launch makes all R*k noisy strips, ONE black-box call labels them, ONE CRNN pass with
         per-replica-group BatchNorm scores them; the per-replica CTC losses come back as a list (same values,
@@ -171,7 +171,8 @@ class TrainerCore:
         if self.backend.gpu_jitter and imgs.is_cuda and R > 1:
             noisy, _ = noiser.batch(imgs, replicas=R)
             ocr_labels = self.ocr.get_labels(noisy.cpu())
-            scores = self.crnn_model(noisy, replica_groups=R)
+            # last_only (area flow): only the last replica's loss is back-propagated -> its samples are the only ones the backward visits
+            scores = self.crnn_model(noisy, replica_groups=R, backward_group=R - 1 if last_only else None)
             out_size = torch.tensor([scores.shape[0]] * k, dtype=torch.int)
             losses = []
             for r in range(R):

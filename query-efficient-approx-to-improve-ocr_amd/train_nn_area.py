@@ -133,7 +133,7 @@ class TrainNNPrep(TrainerCore):
                     total_bb_calls += len(ocr_labels)
                     epoch_bb_calls += len(ocr_labels)
                 if n_skip >= 0:
-                    rep_losses, calls = self._replica_losses(img_preds, noiser, self.inner_limit - n_skip)
+                    rep_losses, calls = self._replica_losses(img_preds, noiser, self.inner_limit - n_skip, last_only=True)
                     total_bb_calls += calls
                     epoch_bb_calls += calls
                     if rep_losses:

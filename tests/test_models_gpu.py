@@ -319,6 +319,56 @@ def test_replica_groups_equal_sequential_passes():
         assert torch.equal(a, b), n
 
 
+@pytest.mark.parametrize("g", [2, 0])
+def test_backward_group_equals_sequential_last_replica(g):
+    """train_nn_area.py:269-271 back-propagates the LAST replica only.  CRNN.forward(backward_group=g) returns the same
+    log-probs (the other groups detached) and its backward visits group g's samples only: the gradients must equal those of
+    the reference-style loop (R sequential passes, backward of pass g alone), the input gradient is zero outside the group,
+    and a loss that touches another group cannot leak a gradient."""
+    from models.model_crnn import CRNN
+    from oracle import model_oracle as mo
+    from qea.loss import CTCLoss
+    R, k = 3, 5
+    sc = mo.seeded_state(mo.crnn_state_shapes(), 11)
+    x = torch.stack([H.synth_images(k, 70 + r) for r in range(R)]).reshape(R * k, 1, 32, 128).cuda()
+    labels = [H.synth_labels(k, 80 + r, 1, 8) for r in range(R)]
+    ins = torch.full((k,), 31, dtype=torch.int)
+
+    def make():
+        net = CRNN(95, False)
+        net.load_state_dict(sc)
+        net = net.cuda().train()
+        net.register_backward_hook(net.backward_hook)
+        net.zero_grad()
+        return net
+    seq = make()
+    xs = x.clone().requires_grad_()
+    lps = []
+    for r in range(R):
+        lp = seq(xs[r * k:(r + 1) * k])
+        lps.append(lp.detach())
+        if r == g:
+            y, ysz = H.encode(labels[r])
+            CTCLoss()(lp, y, ins, ysz).backward()
+    fused = make()
+    xf = x.clone().requires_grad_()
+    lp_all = fused(xf, replica_groups=R, backward_group=g)
+    assert torch.equal(lp_all.detach(), torch.cat(lps, dim=1))
+    y, ysz = H.encode(labels[g])
+    other = (g + 1) % R
+    yo, yosz = H.encode(labels[other])
+    # the second term touches a detached group: it must contribute nothing
+    loss = CTCLoss()(lp_all[:, g * k:(g + 1) * k, :], y, ins, ysz) + CTCLoss()(lp_all[:, other * k:(other + 1) * k, :], yo, ins, yosz)
+    loss.backward()
+    for (n, a), (_, b) in zip(fused.named_parameters(), seq.named_parameters()):
+        assert _rel(a.grad, b.grad) < 2e-5, n
+    for (n, a), (_, b) in zip(fused.named_buffers(), seq.named_buffers()):
+        assert torch.equal(a, b), n
+    assert _rel(xf.grad[g * k:(g + 1) * k], xs.grad[g * k:(g + 1) * k]) < 2e-5
+    outside = torch.cat([xf.grad[:g * k], xf.grad[(g + 1) * k:]])
+    assert outside.abs().max().item() == 0.0
+
+
 def test_fused_adam_resume_matches_uninterrupted(tmp_path):
     """optim_*_latest checkpoints (train_nn_patch.py:153-156,446-454): save after 2 steps, load into a fresh FusedAdam,
     continue -> identical to 3 uninterrupted steps; the state_dict has torch.optim.Adam's layout and loads into it."""
