@@ -259,8 +259,8 @@ def test_area_trainer_one_minibatch_vs_reference(tmp_path, monkeypatch):
     losses = []
     orig = t._replica_losses
 
-    def spy(imgs, noiser, R):
-        out = orig(imgs, noiser, R)
+    def spy(imgs, noiser, R, **kw):
+        out = orig(imgs, noiser, R, **kw)
         losses.extend(l.item() for l in out[0])
         return out
     t._replica_losses = spy
