@@ -1325,6 +1325,12 @@ int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
   if (qea_split_bf16_enabled() && d->tile != -1 && halo_bf3_wins(d)) tile = 24;   // narrow layers: split-bf16 LDS-halo kernel (168-208 vs 95-120 TFLOP/s)
   else if (qea_split_bf16_enabled() && d->N > 32 && d->N <= 64 && a.K >= 256 && d->Cin >= 64) tile = 23;
   else if (halo_eligible(d)) tile = 4;
+  // transposed convolutions (forward scatter / stride-2 input gradient) with K <= 256: traffic-bound launches of 4-16 K
+  // stages; the 8-wave 128x128 split tile has the shortest prologue per output byte (tools/bench_convt.py at B = 2048:
+  // 64->32 fwd 970 -> 821 us, dgrad 708 -> 573; 128->64 604 -> 470 / 320 -> 266; 256->128 343 -> 315 / 224 -> 216)
+  else if (qea_split_bf16_enabled() && (d->out_mode == QEA_OUT_CONVT || (d->stride_h == 2 && d->stride_w == 2)) && d->N >= 64 && a.K >= 64 &&
+           a.K <= 256 && d->Cin % 16 == 0)
+    tile = 25;
   else if (d->N <= 32) tile = 3;
   else if (d->N <= 64) tile = 9;  // 16-deep slice: 51 KB of LDS, three workgroups per CU (107 vs 80 TFLOP/s at 32-deep; the split-bf16 256x64 tile is slower here)
   else if (bf3 && d->N % 256 == 0 && tiles22 >= 512) tile = 22;
