@@ -137,6 +137,9 @@ def cpu_baseline():
             "b128": b128, "b32": b32, "host": host}
 
 
+DOMINANT_KERNEL = "conv3x3_halo_bf3_kernel<64, 128, 4, false>"
+
+
 def source_hash():
     """sha256 (16 hex digits) over the kernel sources: stamps PMC profiles so that a stale one is refused."""
     import hashlib
@@ -355,8 +358,10 @@ def main():
         ops.prof_reset()
         d, _ = timed(fn, steps)
         prof = {k: ops.prof_read(k) for k in (ops.PROF_CONV_IGEMM, ops.PROF_CONV_WGRAD, ops.PROF_LSTM_STEP)}
-        for k in prof:
+        for k in list(prof):
             ops.prof_enable(k, False)
+        # the single dominant kernel of the step (rocprofv3 lists it as conv3x3_halo_bf3_kernel<64, 128, 4, false>)
+        prof["dominant"] = ops.prof_read_tagged(ops.PROF_CONV_IGEMM, ops.prof_tag_halo_bf3(64, 128, False))
         ops.set_overlap(overlap0)
         return prof, d, overlap0
 
@@ -391,7 +396,7 @@ def main():
               "ms_per_step": d1 / args.steps * 1e3}
         del W1
 
-    traffic, traffic_note = None, "no PMC profile for this build"
+    traffic, traffic_dom, traffic_note = None, None, "no PMC profile for this build"
     try:                                             # HBM bytes per launch of the dominant class, from the committed PMC pass of THIS build
         pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         if pm.get("source_hash") != source_hash():
@@ -400,6 +405,8 @@ def main():
             traffic_note = "profiles/r02_pmc_traffic.json was taken on another workload: refused"
         else:
             traffic = pm["conv_igemm"]["hbm_bytes_per_launch"]
+            kt = pm.get("per_kernel_bytes_per_launch", {}).get(DOMINANT_KERNEL)
+            traffic_dom = kt["fetch"] + kt["write"] if kt else None
             traffic_note = "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE in separate passes, profiles/r02_pmc_traffic.json (same sources)"
     except (OSError, KeyError, ValueError):
         pass
@@ -408,6 +415,8 @@ def main():
         ig, wg, ls = prof[ops.PROF_CONV_IGEMM], prof[ops.PROF_CONV_WGRAD], prof[ops.PROF_LSTM_STEP]
         tf = lambda q: q["flops"] / (q["ms"] * 1e-3) / 1e12 if q["ms"] > 0 else 0.0
         ach = tf(ig)
+        dom = prof["dominant"]
+        dom_tf = tf(dom)
         # the class mixes split-bf16 launches (>= 128-channel layers) and native fp32-MFMA launches: its matrix roofline is
         # the flop-weighted harmonic blend of the two peaks (time at peak = flops_split / peak_split + flops_f32 / peak_f32)
         blend = lambda q: 1.0 / ((q["flops_split_bf16"] / q["flops"]) / SPLIT_BF16_PEAK_TFLOPS
@@ -442,21 +451,32 @@ def main():
             "phase_b": {"value": imgs / dt_b, "unit": "patch-images/s", "ms_per_step": dt_b / args.steps * 1e3,
                         "end_to_end_tflops": FLOP_PER_IMG_FAITHFUL * imgs / dt_b / 1e12 if not args.skip_crnn_wgrad else None,
                         "note": "Phase B alone at the same batch: 9.846 GFLOP per image (SURVEY.md §8d unit of work)"},
-            "roofline": {"bound": "mfma", "kernel": "qea_conv_igemm launches (implicit-GEMM conv fwd/dgrad, convT, LSTM/linear GEMMs). Split-bf16 "
-                                                      "(fp32 operands as 3 bf16 planes, six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate): "
-                                                      "conv3x3_halo_bf3_kernel (3x3 layers up to 512 channels, W >= 32: halo split once in LDS, "
-                                                      "filter fragments pre-split), conv_igemm_bf3w_kernel (other >= 128-channel GEMMs: pre-split "
-                                                      "filter planes by LDS-DMA); native v_mfma_f32_32x32x2_f32: conv_igemm_kernel / conv3x3_halo_kernel",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "peak_note": f"fp32-equivalent; flop-weighted blend of bf16 dense peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} "
-                                      f"({100 * f_split:.0f} % of the class's flops run split-bf16) and the fp32 MFMA peak "
-                                      f"{FP32_MFMA_PEAK_TFLOPS}",
-                         "frac_of_native_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS, "split_bf16_flop_fraction": f_split,
-                         "measured": "HIP events around every launch over the same K steps re-run with the wgrad side stream disabled "
-                                     f"({dt_serial / args.steps * 1e3:.2f} ms/step single-stream vs {dt / args.steps * 1e3:.2f} overlapped)",
-                         "traffic": traffic, "traffic_note": traffic_note, "source_hash": source_hash(),
-                         "algorithmic_bytes_per_launch": ig["bytes"] / max(1, ig["launches"]), "launches_per_step": ig["launches"] / args.steps,
-                         "ms_per_step_in_kernel": ig["ms"] / args.steps},
+            "roofline": {"bound": "mfma",
+                         "kernel": DOMINANT_KERNEL + " — the split-bf16 LDS-halo 3x3 convolution (conv_igemm.hip): fp32 operands as 3 bf16 "
+                                   "planes (input halo split once per tile in LDS, filter fragments pre-split), six v_mfma_f32_32x32x16_bf16 "
+                                   "per product, fp32 accumulate; forward and input gradient of every 3x3 layer with >= 64 input and >= 128 "
+                                   "output channels and W % 32 == 0",
+                         "achieved": dom_tf, "peak": SPLIT_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / SPLIT_BF16_PEAK_TFLOPS,
+                         "avg_launch_us": dom["ms"] * 1e3 / max(1, dom["launches"]), "launches_per_step": dom["launches"] / args.steps,
+                         "ms_per_step_in_kernel": dom["ms"] / args.steps, "share_of_step": dom["ms"] / args.steps / (dt_serial / args.steps * 1e3),
+                         "algorithmic_flops_per_launch": dom["flops"] / max(1, dom["launches"]),
+                         "algorithmic_bytes_per_launch": dom["bytes"] / max(1, dom["launches"]),
+                         "traffic": traffic_dom, "traffic_note": traffic_note, "source_hash": source_hash(),
+                         "measured": "HIP events around every launch of this kernel over the same K steps re-run with the wgrad side stream "
+                                     f"disabled ({dt_serial / args.steps * 1e3:.2f} ms/step single-stream vs {dt / args.steps * 1e3:.2f} overlapped); "
+                                     "avg_launch_us is comparable with profiles/r02_kernel_stats_b2048_single_stream.csv",
+                         "peak_is": f"bf16 dense MFMA peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} TFLOP/s fp32-equivalent",
+                         "launch_class": {
+                             "what": "all qea_conv_igemm launches (implicit-GEMM conv fwd/dgrad, convT, LSTM/linear GEMMs): the LDS-halo kernel above, "
+                                     "conv_igemm_bf3w_kernel (other >= 128-channel GEMMs: pre-split filter planes by LDS-DMA), and the native "
+                                     "v_mfma_f32_32x32x2_f32 kernels conv_igemm_kernel / conv3x3_halo_kernel",
+                             "achieved": ach, "peak": peak, "frac": ach / peak, "traffic": traffic,
+                             "algorithmic_bytes_per_launch": ig["bytes"] / max(1, ig["launches"]), "launches_per_step": ig["launches"] / args.steps,
+                             "ms_per_step_in_kernel": ig["ms"] / args.steps, "split_bf16_flop_fraction": f_split,
+                             "frac_of_native_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+                             "peak_note": f"fp32-equivalent; flop-weighted blend of bf16 dense peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} "
+                                          f"({100 * f_split:.0f} % of the class's flops run split-bf16) and the fp32 MFMA peak "
+                                          f"{FP32_MFMA_PEAK_TFLOPS}"}},
             "kernels": {
                 "conv_wgrad": {"tflops": tf(wg), "ms_per_step": wg["ms"] / args.steps, "peak": blend(wg), "frac": tf(wg) / blend(wg),
                                "split_bf16_flop_fraction": wg["flops_split_bf16"] / wg["flops"] if wg["flops"] > 0 else 0.0,

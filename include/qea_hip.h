@@ -49,6 +49,12 @@ int qea_prof_reset(void);
 int qea_prof_read(int klass, double* ms, double* flops, double* bytes, int64_t* launches);
 /* per-launch view of the same records (in launch order): up to `capacity` entries, *count = recorded launches */
 int qea_prof_read_launches(int klass, double* ms, double* flops, int64_t capacity, int64_t* count);
+/* The same sums restricted to the launches one kernel took.  Tags of QEA_PROF_CONV_IGEMM: the tile id, except for the
+ * split-bf16 LDS-halo kernel, whose template instantiation conv3x3_halo_bf3_kernel<CIN, COUT, .., STATS> is
+ * QEA_PROF_TAG_HALO_BF3(CIN, COUT, STATS) — the name rocprofv3 lists it under, so that bench.py's roofline figures of the
+ * dominant kernel can be checked against the kernel trace. */
+#define QEA_PROF_TAG_HALO_BF3(cin_chunk, cout_group, stats) (24000 + ((cin_chunk) == 64 ? 1000 : 0) + (cout_group) + ((stats) ? 500 : 0))
+int qea_prof_read_tagged(int klass, int32_t tag, double* ms, double* flops, double* bytes, int64_t* launches);
 /* The part of a class's algorithmic flops that ran through the split-bf16 kernels (six bf16 MFMAs per fp32
  * multiply-add): bench.py blends the fp32 and the bf16/6 matrix peaks with it. */
 int qea_prof_read_split_bf16(int klass, double* flops);

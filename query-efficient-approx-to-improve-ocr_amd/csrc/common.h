@@ -82,4 +82,4 @@ __device__ __forceinline__ float qea_wave_max(float v) {
 // QEA_MFMA=f32 keeps every product on v_mfma_f32_32x32x2_f32; anything else (default) allows the split-bf16 kernels
 bool qea_split_bf16_enabled();
 void qea_prof_begin(int klass, hipStream_t s);
-void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool split_bf16 = false);
+void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool split_bf16 = false, int tag = 0);

@@ -1471,7 +1471,10 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   if (rc != QEA_OK) return rc;
   // algorithmic bytes: input once + filter once + output once
   const double abytes = 4.0 * ((double)d->B * d->H * d->W * d->Cin + (double)d->N * a.K + (double)a.M * d->N);
-  qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20);
+  // tag = the kernel that ran: QEA_PROF_TAG_CONV(tile, input-channel chunk, output-channel group, fused statistics) for the
+  // LDS-halo split kernel (its template instantiation), the tile id otherwise
+  const int tag = tile == 24 ? QEA_PROF_TAG_HALO_BF3(d->Cin == 32 ? 32 : 64, d->N > 128 ? 128 : d->N, a.stats != nullptr) : tile;
+  qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20, tag);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

@@ -15,7 +15,8 @@ struct ProfClass {
   std::vector<hipEvent_t> start, stop;  // event pool, reused across resets
   size_t used = 0;
   double flops = 0.0, bytes = 0.0, flops_split = 0.0;  // flops_split: the part that ran as split-bf16 MFMAs
-  std::vector<double> launch_flops;
+  std::vector<double> launch_flops, launch_bytes;
+  std::vector<int> launch_tag;              // which kernel took the launch (class-specific code, 0 = unspecified)
   bool open = false;
 };
 ProfClass g_prof[QEA_PROF_NCLASS];
@@ -64,13 +65,15 @@ void qea_prof_begin(int klass, hipStream_t s) {
   pc.open = true;
 }
 
-void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool split_bf16) {
+void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool split_bf16, int tag) {
   ProfClass& pc = g_prof[klass];
   if (!pc.on || !pc.open) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   hipEventRecord(pc.stop[pc.used], s);
   pc.used++;
   pc.launch_flops.push_back(flops);
+  pc.launch_bytes.push_back(bytes);
+  pc.launch_tag.push_back(tag);
   pc.flops += flops;
   pc.bytes += bytes;
   if (split_bf16) pc.flops_split += flops;
@@ -88,6 +91,8 @@ extern "C" int qea_prof_reset(void) {
   for (auto& pc : g_prof) {
     pc.used = 0;
     pc.launch_flops.clear();
+    pc.launch_bytes.clear();
+    pc.launch_tag.clear();
     pc.flops = pc.bytes = pc.flops_split = 0.0;
     pc.open = false;
   }
@@ -112,6 +117,32 @@ extern "C" int qea_prof_read(int klass, double* ms, double* flops, double* bytes
   if (flops) *flops = pc.flops;
   if (bytes) *bytes = pc.bytes;
   if (launches) *launches = (int64_t)pc.used;
+  return QEA_OK;
+}
+
+extern "C" int qea_prof_read_tagged(int klass, int32_t tag, double* ms, double* flops, double* bytes, int64_t* launches) {
+  QEA_REQUIRE(klass >= 0 && klass < QEA_PROF_NCLASS, "qea_prof_read_tagged: bad class %d", klass);
+  ProfClass& pc = g_prof[klass];
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double total = 0.0, fl = 0.0, by = 0.0;
+  int64_t n = 0;
+  for (size_t i = 0; i < pc.used; ++i) {
+    if (pc.launch_tag[i] != tag) continue;
+    if (hipEventSynchronize(pc.stop[i]) != hipSuccess) {
+      qea_set_error("qea_prof_read_tagged: event sync failed");
+      return QEA_ERR_LAUNCH;
+    }
+    float t = 0.f;
+    hipEventElapsedTime(&t, pc.start[i], pc.stop[i]);
+    total += t;
+    fl += pc.launch_flops[i];
+    by += pc.launch_bytes[i];
+    ++n;
+  }
+  if (ms) *ms = total;
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  if (launches) *launches = n;
   return QEA_OK;
 }
 

@@ -245,6 +245,17 @@ def prof_read(klass):
     return {"ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value, "flops_split_bf16": sp.value}
 
 
+def prof_tag_halo_bf3(cin_chunk, cout_group, stats):
+    """QEA_PROF_TAG_HALO_BF3 of include/qea_hip.h"""
+    return 24000 + (1000 if cin_chunk == 64 else 0) + cout_group + (500 if stats else 0)
+
+
+def prof_read_tagged(klass, tag):
+    ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+    _lib.check(_lib.lib().qea_prof_read_tagged(klass, tag, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "qea_prof_read_tagged")
+    return {"ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value}
+
+
 # ----------------------------------------------------------------------------- BN / pool / misc
 def _colws(M, C_, device):
     need = _lib.lib().qea_colreduce_workspace_bytes(M, C_)
