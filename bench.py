@@ -166,6 +166,9 @@ def main():
                     help="skip the CRNN weight gradients the reference computes but discards when --update_CRNN is off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (B = 512) and native-fp32 legs")
+    ap.add_argument("--no-phase-b-leg", action="store_true",
+                    help="skip the Phase-B-only leg too: every step of the run is then the same full step (rocprofv3 runs: the trace's "
+                         "per-kernel averages are then directly comparable with roofline.avg_launch_us)")
     ap.add_argument("--graph", action="store_true",
                     help="record the Phase-B step into a hipGraph and time replays (single GPU, implies --phase-b-only)")
     args = ap.parse_args()
@@ -343,7 +346,7 @@ def main():
         print(f"[bench] {args.steps} timed steps in {dt:.3f}s", file=sys.stderr, flush=True)
     # ---- Phase B alone at the same batch (the per-image unit of SURVEY.md §8d)
     dt_b = dt
-    if not args.phase_b_only:
+    if not args.phase_b_only and not args.no_phase_b_leg:
         phase_b(W)
         dt_b, _ = timed(lambda: phase_b(W), args.steps)
 
@@ -448,7 +451,7 @@ def main():
                        "crnn_wgrad": not args.skip_crnn_wgrad, "parallelism": f"dp{world}",
                        "collectives_per_step": 0 if not use_dist else (1 if args.phase_b_only else 2),
                        "loss": float(loss.item()), "hipgraph": bool(args.graph)},
-            "phase_b": {"value": imgs / dt_b, "unit": "patch-images/s", "ms_per_step": dt_b / args.steps * 1e3,
+            "phase_b": None if (args.no_phase_b_leg and not args.phase_b_only) else {"value": imgs / dt_b, "unit": "patch-images/s", "ms_per_step": dt_b / args.steps * 1e3,
                         "end_to_end_tflops": FLOP_PER_IMG_FAITHFUL * imgs / dt_b / 1e12 if not args.skip_crnn_wgrad else None,
                         "note": "Phase B alone at the same batch: 9.846 GFLOP per image (SURVEY.md §8d unit of work)"},
             "roofline": {"bound": "mfma",

@@ -26,7 +26,7 @@ def main():
             per[n]["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             per[n]["launches"] += 1
     out = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- "
-                     "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary (B=2048 full step, 1x MI355X); summarised by tools/pmc_mfma.py",
+                     "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-phase-b-leg (B=2048 full step, 1x MI355X); summarised by tools/pmc_mfma.py",
            "kernels": {}}
     rows = sorted(per.items(), key=lambda kv: -kv[1]["ns"])
     for n, d in rows:

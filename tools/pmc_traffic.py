@@ -1,7 +1,7 @@
 """HBM bytes per launch of the two MFMA kernel classes from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-phase-b-leg
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-phase-b-leg
   python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 2048 > profiles/r02_pmc_traffic.json
 
 The output carries bench.source_hash() of the kernel sources it was taken on; bench.py refuses a profile of other sources.
