@@ -182,6 +182,11 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
                os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL prints its version block there when a
+    # communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != args.gpus:
@@ -502,7 +507,10 @@ def main():
             out["configs1_b512"] = c1
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
 
