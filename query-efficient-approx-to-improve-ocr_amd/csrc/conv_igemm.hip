@@ -296,7 +296,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvAr
 
 
 // ---------------------------------------------------------------------------------------------
-// EXPERIMENTAL (tile ids 20-22, never chosen automatically): the same implicit GEMM with every fp32 operand split
+// Split-bf16 form (tile ids 20-23, 25; operands split on the fly — the fallback when no pre-split filter planes are given, see
+// conv_igemm_bf3w_kernel / conv_igemm_p3_kernel below): the same implicit GEMM with every fp32 operand split
 // into three bf16 planes x = h + m + l (|x - (h+m+l)| <= 2^-24 |x|) and each product formed by SIX bf16 MFMAs
 // (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll terms are < 2^-23 |ab|) accumulated in fp32:
 // v_mfma_f32_32x32x16_bf16 sustains 1800 TFLOP/s on this part (tools/micro/mfma_rate.hip), i.e. a 300 TFLOP/s
