@@ -1127,28 +1127,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __syncthreads();
       if (chunk + 1 < chunks) gather(cur, chunk + 1, tid);   // in flight under the MFMAs below
       else if (has_next) gather(nxt, 0, tid);                // ... or the next item's first chunk
+      // A fragments of (step, row) — flat index f = st * MI + i — are read ONE fragment row ahead of their MFMAs, across step
+      // boundaries too: the three ds_read_b128 of row f + 1 are issued before the six MFMAs of row f (hipcc otherwise reads just
+      // in time and every row starts with an exposed LDS round trip: 239-250 -> 261-269 TFLOP/s on the 512-channel layers)
+      auto read_a = [&](int st, int i, bf16x8* a) {
+        const int tap = st / KS, cs = st % KS;
+        const int kh = tap / 3, kw = tap % 3;
+        const int hp = (wm * MI + i + kh) * HW_ + fr + kw;
+        const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
+        a[0] = *reinterpret_cast<const bf16x8*>(src);
+        a[1] = *reinterpret_cast<const bf16x8*>(src + PLANE);
+        a[2] = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
+      };
+      bf16x8 ar[2][3];
+      read_a(0, 0, ar[0]);
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
         const int cb = st & 1;                          // STEPS is even for KS = 2, 4: the buffer parity carries over chunks and items
         if (st + 1 < STEPS || chunk + 1 < chunks) load_b(cur.nb, chunk * STEPS + st + 1, cb ^ 1, tid);
         else if (has_next) load_b(nxt.nb, 0, cb ^ 1, tid);
         __builtin_amdgcn_sched_barrier(0);              // keep the next step's filter loads AHEAD of this step's MFMAs
-        const int tap = st / KS, cs = st % KS;
-        const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          const int hp = (wm * MI + i + kh) * HW_ + fr + kw;
-          const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
-          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + PLANE);
-          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
+          const int f = st * MI + i;
+          const bf16x8* a = ar[f & 1];
+          const bool more = f + 1 < STEPS * MI;
+          if (more) read_a((f + 1) / MI, (f + 1) % MI, ar[(f + 1) & 1]);
           // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[cb][0], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cb][2], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cb][1], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[cb][0], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cb][1], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[cb][0], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[cb][0], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][2], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][1], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][0], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][1], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][0], acc[i], 0, 0, 0);
+          if (more) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the three LDS reads of row f + 1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... ahead of the six MFMAs of row f
+          }
         }
       }
     }
