@@ -899,15 +899,23 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
       bf16x8 af[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) af[pl] = frag_p(Ps + pl * P_PLANE, ks * 16 + l_pix);
+      if constexpr (RB == 32) {
+        // (32-wide blocks only: the 64 x 64 variants have no registers to spare — there the second fragment set spills inside
+        // this loop: 512 x 512 249 -> 214 TFLOP/s, while the 32-wide blocks go 152 -> 169 and 172 -> 184)
+      // X fragments one tap ahead of their MFMAs: the six transposing reads of tap t + 1 are issued before the six MFMAs of tap t
+        // (read just in time, every tap started with an exposed LDS round trip)
+        auto read_q = [&](int t, bf16x8* bfr) {
+          const int hq = (py + t / 3) * HW_ + px0 + t % 3 + l_pix;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+          for (int pl = 0; pl < 3; ++pl) bfr[pl] = frag_q(Qs + pl * Q_PLANE, hq);
+        };
+        bf16x8 bq2[2][3];
+        read_q(0, bq2[0]);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int hq = (py + kh) * HW_ + px0 + kw + l_pix;
-          bf16x8 bf[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bf[pl] = frag_q(Qs + pl * Q_PLANE, hq);
-          f32x16& a9 = acc[kh * 3 + kw];
+        for (int t = 0; t < 9; ++t) {
+          const bf16x8* bf = bq2[t & 1];
+          if (t + 1 < 9) read_q(t + 1, bq2[(t + 1) & 1]);
+          f32x16& a9 = acc[t];
           // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of wgrad_bf3_kernel
           a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], a9, 0, 0, 0);
           a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], a9, 0, 0, 0);
@@ -915,7 +923,30 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
           a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], a9, 0, 0, 0);
           a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], a9, 0, 0, 0);
           a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], a9, 0, 0, 0);
+          if (t + 1 < 9) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // the six LDS reads of tap t + 1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... ahead of the six MFMAs of tap t
+          }
         }
+      } else {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int hq = (py + kh) * HW_ + px0 + kw + l_pix;
+            bf16x8 bf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[pl] = frag_q(Qs + pl * Q_PLANE, hq);
+            f32x16& a9 = acc[kh * 3 + kw];
+            // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of wgrad_bf3_kernel
+            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], a9, 0, 0, 0);
+            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], a9, 0, 0, 0);
+            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], a9, 0, 0, 0);
+            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], a9, 0, 0, 0);
+            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], a9, 0, 0, 0);
+            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], a9, 0, 0, 0);
+          }
+      }
     }
   }
   // this wave's 32 x 9 x 32 block of the partial slab of (its split, its k-step share): [R][9][C]
