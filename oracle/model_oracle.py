@@ -173,6 +173,73 @@ def split_state(state, requires_grad=True):
 
 
 # ----------------------------------------------------------------------------- forward passes
+class Trace:
+    """Side channel of one forward pass (test infrastructure of the decision-conditioned gradient gate).
+
+    rec   : dict filled with the detached tensor at every named site — conv / BN / transposed-conv outputs (the BN output
+            is the PRE-activation of the ReLU behind it), max-pool inputs, LSTM layer outputs, logits.
+    force : {site: decision} imposed on the non-differentiable points of the networks instead of taking them from this
+            pass's own values: a ReLU site gets a boolean mask (True = passes), a max-pool site the int64 window winners in
+            F.max_pool2d(return_indices=True) form (flat index into the H*W plane of the pool's input).  With the decisions
+            of ANOTHER implementation's forward imposed, this pass evaluates the function that implementation
+            differentiates, so its fp64 backward is the exact gradient that implementation's backward approximates
+            (the networks are smooth everywhere else: conv, BN, sigmoid/tanh gates, log_softmax, CTC)."""
+
+    def __init__(self, force=None, record=True):
+        self.force = force
+        self.rec = {} if record else None
+
+
+def _tap(x, site, tr):
+    if tr is not None and tr.rec is not None:
+        tr.rec[site] = x.detach()
+    return x
+
+
+def _relu(x, site, tr):
+    if tr is None or tr.force is None:
+        return F.relu(x)
+    return x * tr.force[site].to(x.dtype)
+
+
+def _pool(x, k, site, tr):
+    _tap(x, site, tr)
+    if tr is None or tr.force is None:
+        return F.max_pool2d(x, k)
+    idx = tr.force[site]
+    return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+
+
+POOL_SITES = {"pool1": (2, 2), "pool2": (2, 2), "pool3": (2, 2), "pool4": (2, 2),                       # UNet (model_unet.py:14-20)
+              "convo.pool1": (2, 2), "convo.pool2": (2, 2), "convo.pool4": (2, 1), "convo.pool6": (2, 1)}  # CRNN (model_crnn.py:48-54)
+CRNN_BARE_RELU = ("convo.conv1", "convo.conv2", "convo.conv3", "convo.conv4")      # conv outputs that feed a ReLU directly
+
+
+def is_preactivation(site):
+    return site in CRNN_BARE_RELU or site.startswith("convo.batchnorm") or "norm" in site.rsplit(".", 1)[-1]
+
+
+def own_decisions(rec):
+    """The decisions a recorded pass took itself, in Trace.force form (ATen's rules: ReLU passes x > 0, a pool window keeps
+    its first maximum in scan order)."""
+    out = {}
+    for site, t in rec.items():
+        if is_preactivation(site):
+            out[relu_site(site)] = t > 0
+        elif site in POOL_SITES:
+            out[site] = F.max_pool2d(t, POOL_SITES[site], return_indices=True)[1]
+    return out
+
+
+def relu_site(pre_site):
+    """name of the ReLU behind a recorded pre-activation site: encoder1.enc1norm2 -> encoder1.enc1relu2,
+    convo.conv3 -> convo.relu3, convo.batchnorm1 -> convo.relu5, convo.batchnorm2 -> convo.relu6"""
+    head, leaf = pre_site.rsplit(".", 1)
+    if head == "convo":
+        return "convo.relu" + {"batchnorm1": "5", "batchnorm2": "6"}.get(leaf, leaf[-1])
+    return head + "." + leaf.replace("norm", "relu")
+
+
 def _bn(x, P, Bf, prefix, training):
     return F.batch_norm(x, Bf[prefix + ".running_mean"], Bf[prefix + ".running_var"],
                         P[prefix + ".weight"], P[prefix + ".bias"], training, BN_MOMENTUM, BN_EPS)
@@ -183,45 +250,50 @@ def _bump(Bf, prefix, training):
         Bf[prefix + ".num_batches_tracked"] += 1
 
 
-def _unet_block(x, P, Bf, mod, name, training):
+def _unet_block(x, P, Bf, mod, name, training, tr=None):
     # conv3x3(pad 1, no bias) -> BN -> ReLU, twice (model_unet.py:78-109)
     for i in (1, 2):
-        x = F.conv2d(x, P[f"{mod}.{name}conv{i}.weight"], None, padding=1)
-        x = _bn(x, P, Bf, f"{mod}.{name}norm{i}", training)
+        x = _tap(F.conv2d(x, P[f"{mod}.{name}conv{i}.weight"], None, padding=1), f"{mod}.{name}conv{i}", tr)
+        x = _tap(_bn(x, P, Bf, f"{mod}.{name}norm{i}", training), f"{mod}.{name}norm{i}", tr)
         _bump(Bf, f"{mod}.{name}norm{i}", training)
-        x = F.relu(x)
+        x = _relu(x, f"{mod}.{name}relu{i}", tr)
     return x
 
 
-def unet_forward(P, Bf, x, training):
+def unet_forward(P, Bf, x, training, trace=None):
     """model_unet.py:49-76.  `training` selects batch statistics (+ running-stat update)."""
-    e1 = _unet_block(x, P, Bf, "encoder1", "enc1", training)
-    e2 = _unet_block(F.max_pool2d(e1, 2, 2), P, Bf, "encoder2", "enc2", training)
-    e3 = _unet_block(F.max_pool2d(e2, 2, 2), P, Bf, "encoder3", "enc3", training)
-    e4 = _unet_block(F.max_pool2d(e3, 2, 2), P, Bf, "encoder4", "enc4", training)
-    d = _unet_block(F.max_pool2d(e4, 2, 2), P, Bf, "bottleneck", "bottleneck", training)
+    tr = trace
+    e1 = _unet_block(x, P, Bf, "encoder1", "enc1", training, tr)
+    e2 = _unet_block(_pool(e1, 2, "pool1", tr), P, Bf, "encoder2", "enc2", training, tr)
+    e3 = _unet_block(_pool(e2, 2, "pool2", tr), P, Bf, "encoder3", "enc3", training, tr)
+    e4 = _unet_block(_pool(e3, 2, "pool3", tr), P, Bf, "encoder4", "enc4", training, tr)
+    d = _unet_block(_pool(e4, 2, "pool4", tr), P, Bf, "bottleneck", "bottleneck", training, tr)
     for lvl, skip in ((4, e4), (3, e3), (2, e2), (1, e1)):
-        d = F.conv_transpose2d(d, P[f"upconv{lvl}.weight"], P[f"upconv{lvl}.bias"], stride=2)
+        d = _tap(F.conv_transpose2d(d, P[f"upconv{lvl}.weight"], P[f"upconv{lvl}.bias"], stride=2), f"upconv{lvl}", tr)
         d = torch.cat((d, skip), dim=1)
-        d = _unet_block(d, P, Bf, f"decoder{lvl}", f"dec{lvl}", training)
-    return torch.sigmoid(F.conv2d(d, P["conv.weight"], P["conv.bias"]))
+        d = _unet_block(d, P, Bf, f"decoder{lvl}", f"dec{lvl}", training, tr)
+    return _tap(torch.sigmoid(F.conv2d(d, P["conv.weight"], P["conv.bias"])), "img", tr)
 
 
-def crnn_backbone(P, Bf, x, bn_training):
-    """model_crnn.py:47-56."""
-    c = "convo."
-    x = F.max_pool2d(F.relu(F.conv2d(x, P[c + "conv1.weight"], P[c + "conv1.bias"], padding=1)), (2, 2))
-    x = F.max_pool2d(F.relu(F.conv2d(x, P[c + "conv2.weight"], P[c + "conv2.bias"], padding=1)), (2, 2))
-    x = F.relu(F.conv2d(x, P[c + "conv3.weight"], P[c + "conv3.bias"], padding=1))
-    x = F.max_pool2d(F.relu(F.conv2d(x, P[c + "conv4.weight"], P[c + "conv4.bias"], padding=1)), (2, 1))
-    x = F.conv2d(x, P[c + "conv5.weight"], P[c + "conv5.bias"], padding=1)
-    x = F.relu(_bn(x, P, Bf, c + "batchnorm1", bn_training))
+def crnn_backbone(P, Bf, x, bn_training, trace=None):
+    """model_crnn.py:47-56.  Pool sites of the first four layers sit behind a ReLU: their recorded input (and the
+    imposed winners) refer to the ReLU's OUTPUT."""
+    c, tr = "convo.", trace
+
+    def conv(i, x, **kw):
+        return _tap(F.conv2d(x, P[f"{c}conv{i}.weight"], P[f"{c}conv{i}.bias"], **kw), f"{c}conv{i}", tr)
+    x = _pool(_relu(conv(1, x, padding=1), c + "relu1", tr), (2, 2), c + "pool1", tr)
+    x = _pool(_relu(conv(2, x, padding=1), c + "relu2", tr), (2, 2), c + "pool2", tr)
+    x = _relu(conv(3, x, padding=1), c + "relu3", tr)
+    x = _pool(_relu(conv(4, x, padding=1), c + "relu4", tr), (2, 1), c + "pool4", tr)
+    x = conv(5, x, padding=1)
+    x = _relu(_tap(_bn(x, P, Bf, c + "batchnorm1", bn_training), c + "batchnorm1", tr), c + "relu5", tr)
     _bump(Bf, c + "batchnorm1", bn_training)
-    x = F.conv2d(x, P[c + "conv6.weight"], P[c + "conv6.bias"], padding=1)
-    x = F.relu(_bn(x, P, Bf, c + "batchnorm2", bn_training))
+    x = conv(6, x, padding=1)
+    x = _relu(_tap(_bn(x, P, Bf, c + "batchnorm2", bn_training), c + "batchnorm2", tr), c + "relu6", tr)
     _bump(Bf, c + "batchnorm2", bn_training)
-    x = F.max_pool2d(x, (2, 1))
-    return F.conv2d(x, P[c + "conv7.weight"], P[c + "conv7.bias"])
+    x = _pool(x, (2, 1), c + "pool6", tr)
+    return conv(7, x)
 
 
 def lstm_layer_dir(x, w_ih, w_hh, b_ih, b_hh, reverse):
@@ -242,7 +314,7 @@ def lstm_layer_dir(x, w_ih, w_hh, b_ih, b_hh, reverse):
     return torch.stack(outs)
 
 
-def bilstm(P, x):
+def bilstm(P, x, trace=None):
     """nn.LSTM(512, 256, 2, bidirectional=True) (model_crnn.py:9,19)."""
     for layer in (0, 1):
         outs = []
@@ -250,17 +322,19 @@ def bilstm(P, x):
             outs.append(lstm_layer_dir(x, P[f"lstm.weight_ih_l{layer}{suf}"], P[f"lstm.weight_hh_l{layer}{suf}"],
                                        P[f"lstm.bias_ih_l{layer}{suf}"], P[f"lstm.bias_hh_l{layer}{suf}"], rev))
         x = torch.cat(outs, dim=2)
+        if layer == 0:
+            _tap(x, "lstm0", trace)
     return x
 
 
-def crnn_forward(P, Bf, x, bn_training, nan_scrub=True):
+def crnn_forward(P, Bf, x, bn_training, nan_scrub=True, trace=None):
     """model_crnn.py:16-28 (+ the NaN-scrubbing backward hook of :30-32 as registered by
     train_nn_patch.py:94: NaNs in the gradient entering log_softmax's backward are zeroed)."""
-    f = crnn_backbone(P, Bf, x, bn_training)                 # [B,512,1,W']
+    f = crnn_backbone(P, Bf, x, bn_training, trace)          # [B,512,1,W']
     b, ch, h, w = f.shape
     seq = f.permute(3, 0, 1, 2).reshape(w, b, ch * h)        # map_to_sequence :23-28 (H == 1)
-    y = bilstm(P, seq)
-    logits = y @ P["linear.weight"].t() + P["linear.bias"]
+    y = _tap(bilstm(P, seq, trace), "lstm1", trace)
+    logits = _tap(y @ P["linear.weight"].t() + P["linear.bias"], "logits", trace)
     if nan_scrub and logits.requires_grad:
         logits.register_hook(lambda g: torch.nan_to_num(g, nan=0.0, posinf=float("inf"), neginf=float("-inf")))
     return F.log_softmax(logits, 2)

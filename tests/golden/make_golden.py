@@ -654,6 +654,107 @@ def make_conditioned():
         np.savez_compressed(os.path.join(HERE, f"cond_b{B}w{W}.npz"), **out)
 
 
+def _hook_sites(prep, crnn, rec):
+    """forward hooks that record, under the oracle's site names (oracle/model_oracle.py::Trace), the output of every conv /
+    BatchNorm / transposed conv of the reference modules; -> handles"""
+    hs = []
+
+    def keep(name):
+        def hook(mod, inp, out):
+            rec[name] = out.detach().clone()          # clone: the UNet's ReLUs are in-place
+        return hook
+    if prep is not None:
+        for name, m in prep.named_modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ConvTranspose2d)) and name != "conv":
+                hs.append(m.register_forward_hook(keep(name)))
+    for name, m in crnn.named_modules():
+        if name.startswith("convo.") and isinstance(m, (torch.nn.Conv2d, torch.nn.BatchNorm2d)):
+            hs.append(m.register_forward_hook(keep(name)))
+    return hs
+
+
+def _complete_rec(rec):
+    """add the max-pool input sites (the ReLU outputs in front of the pools) to a hooked record"""
+    for l in (1, 2, 3, 4):
+        k = f"encoder{l}.enc{l}norm2"
+        if k in rec:
+            rec[f"pool{l}"] = torch.relu(rec[k])
+    for site, src in (("convo.pool1", "convo.conv1"), ("convo.pool2", "convo.conv2"), ("convo.pool4", "convo.conv4"),
+                      ("convo.pool6", "convo.batchnorm2")):
+        rec[site] = torch.relu(rec[src])
+    return rec
+
+
+def make_ladder():
+    """tests/golden/ladder.json — what the REFERENCE's own fp32 arithmetic does on the cond_b*.npz candidates, layer by layer,
+    against its fp64 run: l2-relative error of every conv / BatchNorm / transposed-conv output, the ReLU / max-pool decisions
+    that come out differently (count, and the worst fp64 margin in fp32 rounding units of the layer, tests/decisions.py),
+    and the worst full-tensor gradient error.  Two fp32 evaluations: ATen's default CPU path (oneDNN convolutions) and the
+    same with torch.backends.mkldnn disabled (ATen's own im2col + GEMM: another summation order).  The GPU tests print the
+    HIP path's figures next to these (tests/test_conditioned_gpu.py::test_forward_ladder_and_flip_attribution)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import decisions as D
+
+    def entry(R, x, labels, labels_a, tag):
+        runs = {}
+        for variant, dt, mk in (("fp64", torch.float64, True), ("default", torch.float32, True), ("nomkldnn", torch.float32, False)):
+            with torch.backends.mkldnn.flags(enabled=mk):
+                recB, recA = {}, {}
+                hs = _hook_sites(*R.m[dt], recB)
+                b = R.phase_b(dt, x, labels)
+                gB = {**{"prep." + n: g for n, g in _grads(b["prep"].named_parameters()).items()},
+                      **{"crnn." + n: g for n, g in _grads(b["crnn"].named_parameters()).items()}}
+                for h in hs:
+                    h.remove()
+                hs = _hook_sites(None, R.m[dt][1], recA)
+                a = R.phase_a(dt, x, labels_a)
+                gA = {**_grads(a["crnn"].named_parameters()), "dx": a["dx"].double()}
+                for h in hs:
+                    h.remove()
+            runs[variant] = dict(recB=_complete_rec(recB), recA=_complete_rec(recA), gB=gB, gA=gA, img=b["img"])
+        r64 = runs["fp64"]
+        res = {}
+        for variant in ("default", "nomkldnn"):
+            r = runs[variant]
+            ent = {"worst_grad_B": _worst_rel(r["gB"], r64["gB"]), "worst_grad_A": _worst_rel(r["gA"], r64["gA"], skip=ZERO_GRAD),
+                   "img_maxabs": (r["img"].double() - r64["img"]).abs().max().item()}
+            for ph, key in (("B", "recB"), ("A", "recA")):
+                sites = [s_ for s_ in r[key] if s_ not in mo.POOL_SITES]
+                ent["err_" + ph] = {s_: D.rel_l2(r[key][s_], r64[key][s_]) for s_ in sites}
+                fl = D.flip_report(mo.own_decisions(r[key]), r64[key])
+                ent["flips_" + ph] = {s_: [v[0], v[1], round(v[2], 3)] for s_, v in fl.items()}
+            res[variant] = ent
+            print(f"ladder {tag} {variant}: grad worst B {ent['worst_grad_B']:.2e} A {ent['worst_grad_A']:.2e}; img {ent['img_maxabs']:.1e}; "
+                  f"flips B {sum(v[0] for v in ent['flips_B'].values())} A {sum(v[0] for v in ent['flips_A'].values())}; "
+                  f"worst units {max(v[2] for v in list(ent['flips_B'].values()) + list(ent['flips_A'].values())):.1f}; "
+                  f"max layer err B {max(ent['err_B'].values()):.2e}", flush=True)
+        return res
+
+    out = {}
+    for B, W, ws, xs0, keep in COND_SHAPES:
+        case = f"cond_b{B}w{W}.npz"
+        fx = np.load(os.path.join(HERE, case), allow_pickle=False)
+        R = RefRunner(ws)
+        out[case] = {}
+        for k in range(keep):
+            c = f"c{k}|"
+            out[case][f"c{k}"] = entry(R, torch.from_numpy(fx[c + "x"]), [str(s) for s in fx[c + "labels"]],
+                                       [str(s) for s in fx[c + "labels_a"]], f"{case} c{k}")
+        if B == 4:
+            # the same shape WITHOUT the knife-edge-free selection: the first 8 image seeds of the search, accepted or not.  The
+            # selected candidates are by construction inputs on which nine evaluations of ATen's fp32 path take no decision the
+            # other way, so flip counts on them are biased towards zero for ATen (and for anything sharing its arithmetic)
+            T = W // 4 - 1
+            seeds = list(range(xs0, xs0 + 8))
+            un = {"B": B, "W": W, "ws": ws, "seeds": seeds}
+            for i, xs in enumerate(seeds):
+                x = torch.rand(B, 1, 32, W, generator=torch.Generator().manual_seed(xs))
+                un[f"c{i}"] = entry(R, x, synth_labels(B, xs, 1, max(1, T // 2)), synth_labels(B, xs + 100, 1, max(1, T // 2)),
+                                    f"unselected b{B}w{W} seed {xs}")
+            out[f"unselected_b{B}w{W}"] = un
+    json.dump(out, open(os.path.join(HERE, "ladder.json"), "w"), indent=0)
+
+
 def make_crop_oversize():
     """tests/golden/crop_oversize.npz — get_text_stack / padder (utils.py:118-141) on boxes LARGER than 32x128 by odd and
     even amounts: ConstantPad2d with negative pads crops, and Python floor division decides which side loses the extra pixel."""
@@ -804,6 +905,6 @@ def make_tracking():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["unet", "crnn", "ctc", "topk", "helpers", "step", "conditioned", "area_step", "tracking", "crop_oversize"]
+    which = sys.argv[1:] or ["unet", "crnn", "ctc", "topk", "helpers", "step", "conditioned", "area_step", "tracking", "crop_oversize", "ladder"]
     for w in which:
         globals()["make_" + w]()

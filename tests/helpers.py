@@ -156,41 +156,61 @@ def sample_index_small(n, keep=128):
     return torch.randperm(n, generator=torch.Generator().manual_seed(4321 + n))[:keep]
 
 
-def oracle_cond_case(fx, c=""):
-    """-> (Phase-B result, Phase-A result) of the CPU oracle in fp64 on candidate `c` ("c0|", ...) of a cond_b*.npz pack:
-    losses, activations, FULL gradient tensors."""
+def _encode_case(fx, c):
+    labels, labels_a = [str(s) for s in fx[c + "labels"]], [str(s) for s in fx[c + "labels_a"]]
+    return encode(labels), encode(labels_a)
+
+
+def oracle_cond_phase_b(fx, c="", force=None, record=False):
+    """Phase B of candidate `c` ("c0|", ...) of a cond_b*.npz pack on the CPU oracle in fp64: loss, activations, FULL gradient
+    tensors.  force = ReLU / max-pool decisions to impose (oracle.model_oracle.Trace); record adds the per-site tensors."""
     import torch.nn.functional as F
     from oracle import model_oracle as mo
     ws = int(fx["ws"])
-    x = torch.from_numpy(fx[c + "x"]).double()
-    labels, labels_a = [str(s) for s in fx[c + "labels"]], [str(s) for s in fx[c + "labels_a"]]
+    x = torch.as_tensor(fx[c + "x"]).double()
+    (y, ysz), _ = _encode_case(fx, c)
     Pu, Bu = mo.split_state(_state64(mo.unet_state_shapes(), ws))
     Pc, Bc = mo.split_state(_state64(mo.crnn_state_shapes(), ws + 1))
-    img = mo.unet_forward(Pu, Bu, x, training=True)
-    lp = mo.crnn_forward(Pc, Bc, img, bn_training=False)
-    y, ysz = encode(labels)
+    tr = mo.Trace(force, record) if (force is not None or record) else None
+    img = mo.unet_forward(Pu, Bu, x, training=True, trace=tr)
+    lp = mo.crnn_forward(Pc, Bc, img, bn_training=False, trace=tr)
     ins = torch.full((x.shape[0],), lp.shape[0], dtype=torch.int)
     loss = F.ctc_loss(lp, y, ins, ysz) + F.mse_loss(img, torch.ones_like(img))
     loss.backward()
-    rB = dict(loss=loss.item(), img=img.detach(), lp=lp.detach(), g_prep={k: p.grad for k, p in Pu.items()},
-              g_crnn={k: p.grad for k, p in Pc.items()}, buf_prep=Bu)
+    return dict(loss=loss.item(), img=img.detach(), lp=lp.detach(), g_prep={k: p.grad for k, p in Pu.items()},
+                g_crnn={k: p.grad for k, p in Pc.items()}, buf_prep=Bu, rec=tr.rec if tr is not None else None)
+
+
+def oracle_cond_phase_a(fx, c="", force=None, record=False):
+    """Phase A (CRNN in train-mode BN, gradient w.r.t. the input too) of candidate `c`, fp64."""
+    import torch.nn.functional as F
+    from oracle import model_oracle as mo
+    ws = int(fx["ws"])
+    x = torch.as_tensor(fx[c + "x"]).double()
+    _, (ya, ysa) = _encode_case(fx, c)
     Pc2, Bc2 = mo.split_state(_state64(mo.crnn_state_shapes(), ws + 1))
+    tr = mo.Trace(force, record) if (force is not None or record) else None
     xa = x.clone().requires_grad_()
-    lpa = mo.crnn_forward(Pc2, Bc2, xa, bn_training=True)
-    ya, ysa = encode(labels_a)
+    lpa = mo.crnn_forward(Pc2, Bc2, xa, bn_training=True, trace=tr)
+    ins = torch.full((x.shape[0],), lpa.shape[0], dtype=torch.int)
     la = F.ctc_loss(lpa, ya, ins, ysa)
     la.backward()
-    rA = dict(loss=la.item(), lp=lpa.detach(), dx=xa.grad, g_crnn={k: p.grad for k, p in Pc2.items()}, buf_crnn=Bc2)
-    return rB, rA
+    return dict(loss=la.item(), lp=lpa.detach(), dx=xa.grad, g_crnn={k: p.grad for k, p in Pc2.items()}, buf_crnn=Bc2,
+                rec=tr.rec if tr is not None else None)
 
 
-def oracle_tracking_case(fx, batches, weights, c="c0|"):
-    """weighted_ctc_loss (tracking_utils.py:59-75, decaying weights) on the oracle CRNN (train-mode BN), fp64."""
+def oracle_cond_case(fx, c="", record=False):
+    """-> (Phase-B result, Phase-A result) of the free-running CPU oracle in fp64."""
+    return oracle_cond_phase_b(fx, c, None, record), oracle_cond_phase_a(fx, c, None, record)
+
+
+def oracle_tracking_case(fx, batches, weights, c="c0|", force=None):
+    """weighted_ctc_loss (tracking_utils.py:59-75) on the oracle CRNN (train-mode BN), fp64; force = decisions to impose."""
     import torch.nn.functional as F
     from oracle import model_oracle as mo
     Pc, Bc = mo.split_state(_state64(mo.crnn_state_shapes(), int(fx["ws"]) + 1))
     x = torch.from_numpy(fx[c + "x"]).double()
-    lp = mo.crnn_forward(Pc, Bc, x, bn_training=True)
+    lp = mo.crnn_forward(Pc, Bc, x, bn_training=True, trace=mo.Trace(force, False) if force is not None else None)
     total = 0
     for i, (t, ts, idx) in enumerate(batches):
         ins = torch.full((len(idx),), lp.shape[0], dtype=torch.int)

@@ -1,14 +1,22 @@
-"""north_star's gradient gate as written: CTC loss and EVERY gradient tensor of the HIP path within 1e-4 (plain
-|| g - g64 || / || g64 || on the FULL tensor: no element discard, no conditioning term) of the reference evaluated in
-fp64, on the knife-edge-free fixtures tests/golden/cond_b*.npz (how they were selected and why fixtures of that kind only
-exist at a bounded decision count: tests/golden/make_golden.py).  The fp64 yard-stick is the CPU oracle,
-which tests/test_conditioned_cpu.py pins to the reference's own fp64 run to ~1e-10; the HIP result is additionally
-compared DIRECTLY with the reference's fp64 samples stored in the fixture.  Both MFMA modes (split-bf16 default and the
-native fp32 instruction) run under the same bound, and the measured worst error is printed.
+"""north_star's gradient gate: CTC loss and EVERY gradient tensor of the HIP path within 1e-4 — plain
+|| g - g64 || / || g64 || on the FULL tensor: no element discard, no conditioning term, no list of qualified candidates, no
+statistics over runs — on every candidate of every tests/golden/cond_b*.npz pack, both phases, both MFMA modes.
+
+g64 is the CPU oracle's fp64 gradient evaluated UNDER THE ReLU / MAX-POOL DECISIONS THE HIP FORWARD TOOK (tests/decisions.py,
+oracle.model_oracle.Trace): the gradient of a ReLU / max-pool network is a discontinuous function of its forward activations,
+and a decision taken on a pre-activation within rounding of zero moves everything upstream of it by 1e-3..1e-2 — for the
+reference's own fp32 run as much as for this one (tests/golden/ladder.json: the reference with oneDNN disabled flips 22
+decisions on eight unselected 4 x 32x128 inputs).  With the decisions imposed, the oracle differentiates exactly the function
+the HIP backward differentiates, so the comparison is unconditional; the decisions themselves are then accounted for one by
+one (test_forward_ladder_and_flip_attribution): each differing decision must lie within forward-rounding reach of its
+threshold, the per-layer forward error is bounded against the reference's own fp32 figures, and on unselected inputs the HIP
+path may not flip more than twice as many decisions as the reference's fp32 run does.  The free-running fp64 oracle is pinned
+to the reference's fp64 run to ~1e-10 (tests/test_conditioned_cpu.py), and imposing its OWN decisions on it reproduces it
+bit for bit (tests/test_oracle_golden.py::test_forced_own_decisions_change_nothing).
 
 Further down: the label-history CTC against its reference-generated fixture, the product trainer
 train_nn_area.TrainNNPrep itself driven through one minibatch against a reference-generated step, the B = 512 / 2048
-replication property (UNet train-mode BN included) and the document-size patch flow."""
+replication property (UNet train-mode BN included) and the document-size patch flow — all under the same gate."""
 import json
 import math
 import os
@@ -24,7 +32,17 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 GATE = 1e-4
 CASES = ["cond_b2w32.npz", "cond_b4w64.npz", "cond_b4w128.npz"]
+UNSELECTED = ["unselected_b4w64", "unselected_b4w128"]
 ZERO_GRAD = ("convo.conv5.bias", "convo.conv6.bias")     # exactly zero in Phase A (a bias in front of a batch-statistics BN)
+# per-layer forward error allowed against the reference's fp32 run with oneDNN disabled (tests/golden/ladder.json), and the
+# reach of a flipped decision in units of the layer's own measured forward error (rms): see DESIGN.md §4
+LADDER_X = 2.0
+# the CRNN's long reductions (conv4..conv7: K = 2304 / 2304 / 4608 / 2048 products into ONE fp32 accumulator chain, 6 MFMA
+# accumulations per 16 products in the split form, K/2 in the native form; ATen's GEMM blocks K and keeps 16 partial sums per
+# output): rounding model u * sqrt(n_roundings / 2) = 1.0e-6 at K = 4608, measured 0.9e-6
+LADDER_LONG_K = {"convo.relu4": 3.5, "convo.relu5": 3.5, "convo.relu6": 3.5, "convo.conv5": 3.5, "convo.conv6": 3.5, "convo.conv7": 3.5}
+FLIP_REACH = 8.0
+_runs = {}
 
 
 def _bn_eval(m):
@@ -54,77 +72,128 @@ def mfma_mode(request):
     ops.set_mfma_mode(prev)
 
 
-def _qualified():
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cond_qualified.json")
-    return json.load(open(path))
+def _ladder_ref():
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ladder.json")))
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_qualified_candidates_within_1e4(case, mfma_mode):
-    """north_star as written: on the candidates that tools/qualify_fixtures.py found free of decision flips for this mode,
-    the CTC(+MSE) loss and EVERY gradient tensor of both phases within 1e-4 — plain l2-relative error on the full tensor
-    against the fp64 oracle AND against the reference's fp64 samples in the fixture; no discard, no conditioning term."""
+def _pack(case):
     import cond_runner as cr
-    fx = H.golden(case)
-    q = _qualified()[case]
-    assert q["split_bf16"] or q["f32"], f"no qualified candidate at all for {case}: re-run tools/qualify_fixtures.py on the GPU box"
-    ids = q[mfma_mode]
-    if not ids:
-        pytest.skip(f"every candidate of {case} takes some ReLU / max-pool decision the other way in mode {mfma_mode} "
-                    "(tools/qualify_fixtures.py); covered by test_all_candidates_statistics")
-    for ci in ids:
-        r = cr.run_candidate(case, fx, f"c{ci}|")
-        print(f"\n[gate] {case} c{ci} mode={mfma_mode}: worst full-tensor ||g-g64||/||g64|| = {r['worst']:.2e} ({r['worst_tag']}), median {r['median']:.2e},"
-              f" vs fixture samples {r['worst_direct']:.2e}; loss {r['loss_B']:.1e} / {r['loss_A']:.1e};"
-              f" the reference's own fp32 evaluations: {float(np.max(fx[f'c{ci}|variant_worst'])):.2e}")
-        bad = [(k, f"{v:.2e}") for k, v in r["tensor"].items() if v > GATE] + [(k + " (vs fixture)", f"{v:.2e}") for k, v in r["direct"].items() if v > GATE]
-        assert not bad, (ci, sorted(bad, key=lambda kv: -float(kv[1]))[:10])
-        assert r["loss_B"] <= GATE and r["loss_A"] <= GATE and r["img"] < 1e-5 and r["lp"] < 1e-4 and r["buf"] <= 1e-5 and r["zero"] <= 1e-6
+    return cr.unselected_pack(_ladder_ref()[case]) if case.startswith("unselected") else H.golden(case)
 
 
-def test_all_candidates_statistics():
-    """The same comparison over EVERY candidate (20) in both modes, stated so that it does not depend on which candidates
-    happen to be flip-free for this build (a ReLU / max-pool decision taken the other way moves the gradients UPSTREAM of it
-    by 1e-3..1e-2 and nothing else — DESIGN.md §4):
-      * always: losses within 1e-4, forward activations within 1e-5 / 1e-4, BN statistics within 1e-5, no tensor off by more
-        than 5e-2, and the best quarter of the tensors within 1e-5 (a flip near the loss moves everything upstream of it —
-        most of the network — but never the layers behind it);
-      * every tensor is within 1e-4 in at least half of the (candidate, mode) runs (a systematic error of one tensor — a
-        mis-scaled BN term, a wrong bias gradient — fails every run);
-      * at least a quarter of the runs are within 1e-4 on every tensor."""
+def _run(case, mode, ci):
+    """one (pack, MFMA mode, candidate) through tests/cond_runner.py, shared by the tests of this module"""
     import cond_runner as cr
-    from qea import ops
-    runs, per_tensor = [], {}
-    for case in CASES:
-        fx = H.golden(case)
-        for mode in ("split_bf16", "f32"):
-            prev = ops.set_mfma_mode(mode)
-            try:
-                for ci in range(int(fx["n_candidates"])):
-                    r = cr.run_candidate(case, fx, f"c{ci}|")
-                    runs.append((case, mode, ci, r))
-                    assert r["loss_B"] <= GATE and r["loss_A"] <= GATE, (case, mode, ci, r["loss_B"], r["loss_A"])
-                    assert r["img"] < 1e-5 and r["lp"] < 1e-4 and r["buf"] <= 1e-5 and r["zero"] <= 1e-6, (case, mode, ci, r["img"], r["lp"], r["buf"], r["zero"])
-                    v = sorted(r["tensor"].values())
-                    assert v[len(v) // 4] <= 1e-5 and v[-1] <= 5e-2, (case, mode, ci, v[len(v) // 4], v[-1])
-                    for k, v in r["tensor"].items():
-                        per_tensor.setdefault(k, []).append(v)
-            finally:
-                ops.set_mfma_mode(prev)
-    clean = [(c, m, i) for c, m, i, r in runs if r["worst"] <= GATE]
-    print(f"\n[gate] {len(clean)} of {len(runs)} (candidate, mode) runs within 1e-4 on every tensor; medians "
-          f"{min(r['median'] for *_, r in runs):.1e}..{max(r['median'] for *_, r in runs):.1e}; worst over clean runs "
-          f"{max((r['worst'] for *_, r in runs if r['worst'] <= GATE), default=float('nan')):.2e}")
-    for k, v in per_tensor.items():
-        assert sum(e <= GATE for e in v) * 2 >= len(v), (k, sorted(v))
-    assert len(clean) * 4 >= len(runs), [(c, m, i, f"{r['worst']:.1e}") for c, m, i, r in runs]
+    key = (case, mode, ci)
+    if key not in _runs:
+        _runs[key] = cr.run_candidate(case, _pack(case), f"c{ci}|")
+    return _runs[key]
+
+
+@pytest.mark.parametrize("case", CASES + UNSELECTED)
+def test_gradients_within_1e4_decision_conditioned(case, mfma_mode):
+    """north_star as written, on EVERY candidate (and on the unselected inputs of the same shapes): loss within 1e-4 of the
+    reference's fp64 loss, every gradient tensor of both phases within the plain full-tensor 1e-4 of the fp64 oracle under
+    the HIP forward's decisions; forward activations, log-probs and BN statistics against the reference's fp64 run."""
+    fx = _pack(case)
+    worst = (0.0, None)
+    for ci in range(int(fx["n_candidates"])):
+        r = _run(case, mfma_mode, ci)
+        bad = [(k, f"{v:.2e}") for k, v in r["tensor"].items() if not v <= GATE]
+        assert not bad, (case, ci, sorted(bad, key=lambda kv: -float(kv[1]))[:10])
+        assert r["loss_B"] <= GATE and r["loss_A"] <= GATE and r["img"] < 2e-6 and r["lp"] < 1e-5 and r["buf"] <= 1e-5 and r["zero"] <= 1e-6, \
+            (case, ci, r["loss_B"], r["loss_A"], r["img"], r["lp"], r["buf"], r["zero"])
+        worst = max(worst, (r["worst"], f"c{ci} {r['worst_tag']}"))
+        print(f"\n[gate] {case} c{ci} mode={mfma_mode}: worst ||g-g64||/||g64|| under the HIP decisions {r['worst']:.2e} ({r['worst_tag']}), median "
+              f"{r['median']:.2e}; {r['n_flips']} decisions differ from the fp64 oracle's own -> against the FREE oracle {r['worst_free']:.2e};"
+              f" loss {r['loss_B']:.1e} / {r['loss_A']:.1e}, img {r['img']:.1e}, lp {r['lp']:.1e}")
+    print(f"\n[gate] {case} mode={mfma_mode}: worst over all candidates {worst[0]:.2e} ({worst[1]})")
+
+
+def _pre_site(site):
+    if "relu" not in site:
+        return site
+    head, leaf = site.rsplit(".", 1)
+    if head == "convo":
+        return {"5": "convo.batchnorm1", "6": "convo.batchnorm2"}.get(leaf[-1], "convo.conv" + leaf[-1])
+    return head + "." + leaf.replace("relu", "norm")
+
+
+def _layer_of(site):
+    """decision site -> the HIP tap whose error bounds the decision's reach (a pool decides on the ReLU output in front of it)"""
+    if site.startswith("convo.pool"):
+        return "convo.relu" + site[-1]
+    if site.startswith("pool"):
+        return f"encoder{site[-1]}.enc{site[-1]}relu2"
+    return site
+
+
+def test_forward_ladder_and_flip_attribution(mfma_mode):
+    """VERDICT r2 next #1 (b), (c).
+    LADDER: l2-relative error of every conv / BatchNorm+ReLU / transposed-conv output of the HIP forward against the fp64 oracle,
+    next to the same figure of the reference's fp32 run (ATen default, and with oneDNN disabled) from tests/golden/ladder.json:
+    no layer may exceed LADDER_X (2) times the oneDNN-off figure, the CRNN's long-K layers LADDER_LONG_K (3.5) times.
+    FLIPS: a decision that differs from the fp64 oracle's must have its fp64 margin (|pre-activation|, or the gap between the
+    window maximum and the element kept) within FLIP_REACH times the rms forward error measured for that very layer — i.e. it
+    is a consequence of forward rounding and of nothing else; counts are printed per layer.
+    RATE: on the UNSELECTED inputs (the cond_* candidates are, by construction, inputs on which ATen's fp32 path takes no
+    decision the other way) the HIP path flips at most twice as many decisions as the reference's fp32 run with oneDNN off."""
+    ref = _ladder_ref()
+    over, unreach, per_site = [], [], {}
+    totals = {}
+    for case in CASES + UNSELECTED:
+        n = int(_pack(case)["n_candidates"])
+        t = totals.setdefault(case, dict(hip=0, default=0, nomkldnn=0, hip_runs=0, default_runs=0, nomkldnn_runs=0, n=n))
+        for ci in range(n):
+            r = _run(case, mfma_mode, ci)
+            cpu = ref[case][f"c{ci}"]
+            for k, e in r["ladder"].items():
+                ph, site = k.split("|", 1)
+                base = cpu["nomkldnn"]["err_" + ph].get(_pre_site(site))
+                if base is not None and e > LADDER_LONG_K.get(site, LADDER_X) * base:
+                    over.append((case, ci, k, f"{e:.2e}", f"{base:.2e}", round(e / base, 2)))
+            for k, (nf, nd, units) in r["flips"].items():
+                if not nf:
+                    continue
+                ph, site = k.split("|", 1)
+                s = per_site.setdefault(site, [0, 0.0])
+                s[0] += nf
+                s[1] = max(s[1], units)
+                reach = FLIP_REACH * max(r["ladder"][ph + "|" + _layer_of(site)] / 2.0 ** -23, 1.0)
+                if units > reach:
+                    unreach.append((case, ci, k, nf, round(units, 1), round(reach, 1)))
+            t["hip"] += r["n_flips"]
+            t["hip_runs"] += r["n_flips"] > 0
+            for v in ("default", "nomkldnn"):
+                f = sum(x[0] for x in cpu[v]["flips_B"].values()) + sum(x[0] for x in cpu[v]["flips_A"].values())
+                t[v] += f
+                t[v + "_runs"] += f > 0
+    print(f"\n[flips] mode={mfma_mode}: decisions differing from the fp64 oracle's, per layer (count, worst margin in fp32 rounding units): "
+          + ", ".join(f"{k}: {v[0]} ({v[1]:.1f})" for k, v in sorted(per_site.items())))
+    for case, t in totals.items():
+        print(f"[flips] {case}: HIP {t['hip']} decisions in {t['hip_runs']} of {t['n']} inputs; reference fp32 default {t['default']} in {t['default_runs']},"
+              f" oneDNN off {t['nomkldnn']} in {t['nomkldnn_runs']}")
+    r0 = _run("cond_b4w128.npz", mfma_mode, 0)
+    c0 = ref["cond_b4w128.npz"]["c0"]
+    print("[ladder] cond_b4w128 c0, l2-relative forward error per layer: HIP | reference fp32 default | oneDNN off")
+    for k, e in r0["ladder"].items():
+        ph, site = k.split("|", 1)
+        d, n_ = c0["default"]["err_" + ph].get(_pre_site(site)), c0["nomkldnn"]["err_" + ph].get(_pre_site(site))
+        if d is not None:
+            print(f"[ladder]   {k:34s} {e:.2e} | {d:.2e} | {n_:.2e}")
+    assert not over, sorted(over, key=lambda v: -v[-1])[:12]
+    assert not unreach, unreach[:12]
+    hip = sum(totals[c]["hip"] for c in UNSELECTED)
+    cpu = sum(totals[c]["nomkldnn"] for c in UNSELECTED)
+    assert hip <= 2 * cpu, (hip, cpu)
 
 
 def test_label_history_ctc_vs_reference():
     """a14 / f3: generate_ctc_target_batches + weighted_ctc_loss (tracking_utils.py:42-81) with decaying weights
-    (label_tracking/tracking_methods.py:105-115) on the HIP CRNN: loss and every gradient against the fixture produced by the
-    REFERENCE's tracking_utils (3-epoch ragged history, window 3, decay 0.7), four image candidates x two MFMA modes, with the
-    requirement stated as in test_all_candidates_statistics."""
+    (label_tracking/tracking_methods.py:105-115) on the HIP CRNN: the loss against the fixture produced by the REFERENCE's
+    tracking_utils (3-epoch ragged history, window 3, decay 0.7), every gradient tensor within 1e-4 of the fp64 oracle under
+    the HIP forward's decisions; four image candidates x two MFMA modes."""
+    import decisions as D
     import tracking_utils as tu
     from label_tracking.tracking_methods import weightgenerator_factory
     from qea import ops
@@ -132,7 +201,7 @@ def test_label_history_ctc_vs_reference():
     fx = H.golden("tracking_b6.npz")
     names = [str(s) for s in fx["names"]]
     dev = torch.device("cuda")
-    runs, per_tensor = [], {}
+    runs = []
     for mode in ("split_bf16", "f32"):
         prev = ops.set_mfma_mode(mode)
         try:
@@ -148,31 +217,19 @@ def test_label_history_ctc_vs_reference():
                 tu.add_labels_to_history(self, names, [str(s) for s in fx["current"]])
                 batches = tu.generate_ctc_target_batches(self, names)
                 scores, pred_size = tu.call_crnn(self, torch.from_numpy(fx[c + "x"]))
+                force, _ = D.hip_crnn_trace(scores.grad_fn.saved)
                 loss = tu.weighted_ctc_loss(self, scores, pred_size, batches, w)
                 loss.backward()
                 assert abs(loss.item() - float(fx[c + "loss64"])) <= GATE * float(fx[c + "loss64"])
-                assert (scores.detach().cpu().double() - torch.from_numpy(fx[c + "lp64"])).abs().max().item() < 1e-4
-                r = H.oracle_tracking_case(fx, [(t, ts, idx) for t, ts, idx in batches], w.cpu(), c)
-                errs = {}
-                for name, p in crnn.named_parameters():
-                    if name in ZERO_GRAD:
-                        continue
-                    errs[name] = H.full_rel_err(p.grad, r["g_crnn"][name])
-                    s64 = torch.from_numpy(fx[f"{c}g|{name}|s64"]).double()
-                    g = p.grad.double().flatten().cpu()[H.sample_index_small(p.numel())]
-                    l264 = float(fx[f"{c}g|{name}|l264"])
-                    errs[name] = max(errs[name], (g - s64).norm().item() / max(s64.norm().item(), l264 * (s64.numel() / p.numel()) ** 0.5))
-                    per_tensor.setdefault(name, []).append(errs[name])
-                v = sorted(errs.values())
-                assert v[len(v) // 4] <= 1e-5 and v[-1] <= 5e-2, (mode, ci, v[len(v) // 4], v[-1])
-                runs.append((mode, ci, v[-1]))
+                assert (scores.detach().cpu().double() - torch.from_numpy(fx[c + "lp64"])).abs().max().item() < 1e-5
+                r = H.oracle_tracking_case(fx, [(t, ts, idx) for t, ts, idx in batches], w.cpu(), c, force=force)
+                errs = {name: H.full_rel_err(p.grad, r["g_crnn"][name]) for name, p in crnn.named_parameters() if name not in ZERO_GRAD}
+                bad = {k: f"{v:.2e}" for k, v in errs.items() if not v <= GATE}
+                assert not bad, (mode, ci, bad)
+                runs.append((mode, ci, max(errs.values())))
         finally:
             ops.set_mfma_mode(prev)
-    clean = [r for r in runs if r[2] <= GATE]
-    print(f"\n[gate] label-history CTC: {len(clean)} of {len(runs)} runs within 1e-4 on every tensor: {[(m, i, f'{e:.1e}') for m, i, e in runs]}")
-    for k, v in per_tensor.items():
-        assert sum(e <= GATE for e in v) * 2 >= len(v), (k, sorted(v))
-    assert len(clean) * 4 >= len(runs)
+    print(f"\n[gate] label-history CTC, worst gradient error under the HIP decisions per run: {[(m, i, f'{e:.1e}') for m, i, e in runs]}")
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -326,9 +383,10 @@ def test_replicated_batch_equals_small_batch_oracle(Bfull):
     """BASELINE configs[1] / configs[2] batch sizes with the UNet in train-mode BN.  Size-independent
     property: a batch made of R copies of 8 images has the SAME batch statistics as the 8 images, so the mean-reduced loss,
     every parameter gradient and the BN running means equal the 8-image oracle result (running variances up to the unbiased
-    n/(n-1) factor).  At B = 512 / 2048 every layer runs the tile configuration of the bench shapes.  Decision flips
-     make 1e-4 unattainable for an 8-image case in general, so the gradient bound here is 2e-2 per tensor
-    (an indexing / tiling error is O(1)); the loss and the statistics are held to 1e-4 / 1e-5."""
+    n/(n-1) factor).  At B = 512 / 2048 every layer runs the tile configuration of the bench shapes.  Every replica takes the
+    same ReLU / max-pool decisions (asserted: identical arithmetic per replica); with the decisions of the first 8 samples
+    imposed on the 8-image fp64 oracle every gradient tensor is held to the plain 1e-4, the loss to 1e-4, statistics to 1e-5."""
+    import decisions as D
     from oracle import model_oracle as mo
     from qea.loss import CTCLoss
     ws, n = 60, 8
@@ -342,26 +400,31 @@ def test_replicated_batch_equals_small_batch_oracle(Bfull):
     y, ysz = H.encode(labels8 * R)
     img = prep(x)
     lp = crnn(img)
+    su, sc = img.grad_fn.saved, lp.grad_fn.saved
+    fu, _ = D.hip_unet_trace(su, first=n)
+    fc, _ = D.hip_crnn_trace(sc, first=n)
+    # every replica sees identical arithmetic: outputs and the decisions of the deepest / widest layers
+    assert torch.equal(img[:n], img[n * (R - 1):]) and torch.equal(lp[:, :n], lp[:, n * (R - 1):])
+    for t in (su["blocks"]["bottleneck"]["out"], su["blocks"]["decoder1"]["a1"], sc["acts"]["a6"], sc["acts"]["a2"]):
+        rows = t.shape[0] // Bfull
+        assert torch.equal(t[:n * rows] > 0, t[(Bfull - n) * rows:] > 0)
     loss = CTCLoss()(lp, y, torch.full((Bfull,), 31, dtype=torch.int), ysz) + F.mse_loss(img, torch.ones_like(img))
     loss.backward()
     torch.cuda.synchronize()
-    # every replica sees identical arithmetic
-    assert torch.equal(img[:n], img[n * (R - 1):]) and torch.equal(lp[:, :n], lp[:, n * (R - 1):])
     Pu, Bu = mo.split_state(H._state64(mo.unet_state_shapes(), ws))
     Pc, Bc = mo.split_state(H._state64(mo.crnn_state_shapes(), ws + 1))
-    img_r = mo.unet_forward(Pu, Bu, x8.double(), training=True)
-    lp_r = mo.crnn_forward(Pc, Bc, img_r, bn_training=False)
+    tr = mo.Trace({**fu, **fc}, record=False)
+    img_r = mo.unet_forward(Pu, Bu, x8.double(), training=True, trace=tr)
+    lp_r = mo.crnn_forward(Pc, Bc, img_r, bn_training=False, trace=tr)
     y8, ysz8 = H.encode(labels8)
     loss_r = F.ctc_loss(lp_r, y8, torch.full((n,), 31, dtype=torch.int), ysz8) + F.mse_loss(img_r, torch.ones_like(img_r))
     loss_r.backward()
     assert abs(loss.item() - loss_r.item()) <= 1e-4 * abs(loss_r.item())
-    assert (img[:n].cpu().double() - img_r.detach()).abs().max().item() < 2e-5
-    worst = 0.0
-    for name, p in list(prep.named_parameters()) + list(crnn.named_parameters()):
-        ref = (Pu[name] if name in Pu else Pc[name]).grad
-        e = H.full_rel_err(p.grad, ref)
-        worst = max(worst, e)
-        assert e <= 2e-2, (name, e)
+    assert (img[:n].cpu().double() - img_r.detach()).abs().max().item() < 2e-6
+    errs = {name: H.full_rel_err(p.grad, (Pu[name] if name in Pu else Pc[name]).grad)
+            for name, p in list(prep.named_parameters()) + list(crnn.named_parameters())}
+    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v <= GATE}
+    assert not bad, bad
     for name, b in prep.named_buffers():
         if name.endswith("running_mean"):
             assert (b.cpu().double() - Bu[name]).abs().max().item() <= 1e-5 * max(1.0, Bu[name].abs().max().item()), name
@@ -372,7 +435,8 @@ def test_replicated_batch_equals_small_batch_oracle(Bfull):
             var8 = (Bu[name] - 0.9) / 0.1 * (cnt8 - 1) / cnt8
             want = 0.9 + 0.1 * var8 * cnt / (cnt - 1)
             assert (b.cpu().double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), name
-    print(f"\n[replicated] B={Bfull}: worst full-tensor gradient error vs the 8-image fp64 oracle {worst:.2e}")
+    print(f"\n[replicated] B={Bfull}: worst full-tensor gradient error vs the 8-image fp64 oracle under the HIP decisions "
+          f"{max(errs.values()):.2e} ({max(errs, key=errs.get)})")
 
 
 def _bn_pixels(name):
@@ -385,8 +449,9 @@ def _bn_pixels(name):
 def test_document_patch_flow_vs_oracle():
     """f2 (train_nn_patch.py:237-242,318-329; utils.py:118-141): UNet(train) on a whole [1,1,400,512] document -> crop+pad
     gather of the text strips -> CRNN(BN eval) -> CTC + scalar*MSE over the WHOLE page -> backward through the scatter-add
-    into the document-sized gradient -> UNet backward; against the CPU oracle in fp64.  One image: the UNet's BN statistics
-    are over 204 800 pixels per channel at level 1; gradient bound 2e-2 per tensor (decision flips), loss 1e-4."""
+    into the document-sized gradient -> UNet backward; against the CPU oracle in fp64 under the HIP forward's decisions.
+    One image: the UNet's BN statistics are over 204 800 pixels per channel at level 1.  Loss 1e-4, every gradient tensor 1e-4."""
+    import decisions as D
     import utils
     from oracle import model_oracle as mo
     from oracle import path_oracle as po
@@ -402,9 +467,12 @@ def test_document_patch_flow_vs_oracle():
     prep, crnn = _hip_models(ws)
     prep.train(); crnn.train(); _bn_eval(crnn)
     prep.zero_grad(); crnn.zero_grad()
-    out = prep(page.cuda())[0]
+    full = prep(page.cuda())
+    out = full[0]
     crops, labels = utils.get_text_stack(out, boxes, (32, 128))
     lp = crnn(crops)
+    fu, _ = D.hip_unet_trace(full.grad_fn.saved)
+    fc, _ = D.hip_crnn_trace(lp.grad_fn.saved)
     y, ysz = H.encode(labels)
     n = len(labels)
     loss = CTCLoss()(lp, y, torch.full((n,), 31, dtype=torch.int), ysz) + F.mse_loss(out, torch.ones_like(out))
@@ -412,22 +480,23 @@ def test_document_patch_flow_vs_oracle():
     torch.cuda.synchronize()
     Pu, Bu = mo.split_state(H._state64(mo.unet_state_shapes(), ws))
     Pc, Bc = mo.split_state(H._state64(mo.crnn_state_shapes(), ws + 1))
-    out_r = mo.unet_forward(Pu, Bu, page.double(), training=True)[0]
+    tr = mo.Trace({**fu, **fc}, record=False)
+    out_r = mo.unet_forward(Pu, Bu, page.double(), training=True, trace=tr)[0]
     crops_r = torch.stack([F.pad(out_r[:, b["y_min"]:b["y_max"], b["x_min"]:b["x_max"]],
                                  ((128 - (b["x_max"] - b["x_min"])) // 2, 128 - (128 - (b["x_max"] - b["x_min"])) // 2 - (b["x_max"] - b["x_min"]),
                                   (32 - (b["y_max"] - b["y_min"])) // 2, 32 - (32 - (b["y_max"] - b["y_min"])) // 2 - (b["y_max"] - b["y_min"])), value=1.0)
                            for b in boxes])
     st_np, _ = po.text_stack(out_r.detach().numpy(), boxes, (32, 128))            # the oracle's restatement agrees with the autograd form
     assert np.abs(st_np - crops_r.detach().numpy()).max() == 0
-    lp_r = mo.crnn_forward(Pc, Bc, crops_r, bn_training=False)
+    lp_r = mo.crnn_forward(Pc, Bc, crops_r, bn_training=False, trace=tr)
     loss_r = F.ctc_loss(lp_r, y, torch.full((n,), 31, dtype=torch.int), ysz) + F.mse_loss(out_r, torch.ones_like(out_r))
     loss_r.backward()
     assert abs(loss.item() - loss_r.item()) <= 1e-4 * abs(loss_r.item())
-    assert (out.detach().cpu().double() - out_r.detach()).abs().max().item() < 2e-5
-    assert (crops.detach().cpu().double() - crops_r.detach()).abs().max().item() < 2e-5
-    worst = 0.0
-    for name, p in list(prep.named_parameters()) + list(crnn.named_parameters()):
-        e = H.full_rel_err(p.grad, (Pu[name] if name in Pu else Pc[name]).grad)
-        worst = max(worst, e)
-        assert e <= 2e-2, (name, e)
-    print(f"\n[patch flow] [1,1,400,512] document, {n} strips: worst full-tensor gradient error {worst:.2e}")
+    assert (out.detach().cpu().double() - out_r.detach()).abs().max().item() < 2e-6
+    assert (crops.detach().cpu().double() - crops_r.detach()).abs().max().item() < 2e-6
+    errs = {name: H.full_rel_err(p.grad, (Pu[name] if name in Pu else Pc[name]).grad)
+            for name, p in list(prep.named_parameters()) + list(crnn.named_parameters())}
+    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v <= GATE}
+    assert not bad, bad
+    print(f"\n[patch flow] [1,1,400,512] document, {n} strips: worst full-tensor gradient error under the HIP decisions "
+          f"{max(errs.values()):.2e} ({max(errs, key=errs.get)})")
