@@ -157,7 +157,7 @@ class TrainNNPrep(TrainerCore):
             self._epoch_jsons(epoch)
             if self.lr_scheduler:
                 self.scheduler_crnn.step()
-            val = self._validate()
+            val = self._validate(epoch)
             val.update({"Epoch": epoch + 1, "train_loss": training_loss / max(1, step), "Total Black-Box Calls": total_bb_calls,
                         "Black-Box Calls": epoch_bb_calls, "CRNN_loss": CRNN_training_loss / max(1, epoch_bb_calls)})
             self.log.log(val)
@@ -166,7 +166,7 @@ class TrainNNPrep(TrainerCore):
         print("Training Completed.")
         return best
 
-    def _validate(self):
+    def _validate(self, epoch=0):
         self.prep_model.eval()
         self.crnn_model.eval()
         cnt = dict(crnn=0, ocr=0, match=0)
@@ -186,7 +186,9 @@ class TrainNNPrep(TrainerCore):
                     cer[key] += e
                 nb += 1
         if self.rank == 0 and img_preds is not None:
-            save_img(img_preds.cpu(), "out_" + str(getattr(self, "_epoch_for_img", 0)), self.img_out_path, 8)
+            save_img(img_preds.cpu(), "out_" + str(epoch), self.img_out_path, 8)          # train_nn_area.py:373
+            if epoch == 0:
+                save_img(images.cpu(), "out_original", self.img_out_path, 8)              # :374-375
         n = max(1, nb * self.batch_size)
         return {"CRNN_accuracy": cnt["crnn"] / n, f"{self.ocr_name}_accuracy": cnt["ocr"] / n, "CRNN_CER": cer["crnn"] / n,
                 f"{self.ocr_name}_cer": cer["ocr"] / n, "CRNN_OCR_Matching_ACC": cnt["match"] / n,

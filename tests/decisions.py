@@ -25,9 +25,24 @@ UNET_BLOCKS = (("encoder1", "enc1"), ("encoder2", "enc2"), ("encoder3", "enc3"),
                ("decoder4", "dec4"), ("decoder3", "dec3"), ("decoder2", "dec2"), ("decoder1", "dec1"))
 
 
-def _nchw(t, B, h, w):
-    """[>= B*h*w][C] NHWC rows (possibly a strided column slice) -> the first B samples as [B,C,h,w] on the CPU"""
-    return t.detach()[:B * h * w].reshape(B, h, w, t.shape[-1]).permute(0, 3, 1, 2).contiguous().cpu()
+def _nchw(t, B, h, w, start=0):
+    """[>= (start+B)*h*w][C] NHWC rows (possibly a strided column slice) -> samples start .. start+B as [B,C,h,w] on the CPU"""
+    return t.detach()[start * h * w:(start + B) * h * w].reshape(B, h, w, t.shape[-1]).permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def saved_of(t):
+    """the context an engine kept for its backward, found on the autograd node (UNetFn / CRNNFn) that produced tensor t —
+    directly or through the slices / cat the model wraps around it (CRNN.forward(backward_group=...))"""
+    todo, seen = [t.grad_fn], set()
+    while todo:
+        fn = todo.pop(0)
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        if isinstance(getattr(fn, "saved", None), dict):
+            return fn.saved
+        todo.extend(f for f, _ in fn.next_functions)
+    raise RuntimeError("no engine context behind this tensor (was the backward already run?)")
 
 
 def hip_unet_trace(saved, first=None):
@@ -53,25 +68,26 @@ def hip_unet_trace(saved, first=None):
     return force, taps
 
 
-def hip_crnn_trace(saved, first=None):
-    """the same for CRNNEngine.forward's context (lp.grad_fn.saved)."""
+def hip_crnn_trace(saved, first=None, start=0):
+    """the same for CRNNEngine.forward's context (lp.grad_fn.saved); samples start .. start + first of the batch."""
     B, H, W, T = first or saved["B"], saved["H"], saved["W"], saved["T"]
+    b0 = start
     acts, dims = saved["acts"], saved["dims"]
     force, taps = {}, {}
     for k in "123456":
         h, w = dims["conv" + k]
-        act = _nchw(acts["a" + k], B, h, w)
+        act = _nchw(acts["a" + k], B, h, w, b0)
         taps["convo.relu" + k] = act
         force["convo.relu" + k] = act > 0
         if "convo.pool" + k in mo.POOL_SITES:
             force["convo.pool" + k] = F.max_pool2d(act, mo.POOL_SITES["convo.pool" + k], return_indices=True)[1]
     for k in "56":
         h, w = dims["conv" + k]
-        taps["convo.conv" + k] = _nchw(acts["y" + k], B, h, w)
+        taps["convo.conv" + k] = _nchw(acts["y" + k], B, h, w, b0)
     seq = saved["lstm"][0]["x"]                                     # conv7's output, written as [T][B][512]
-    taps["convo.conv7"] = seq.detach()[:, :B].permute(1, 2, 0).unsqueeze(2).contiguous().cpu()
-    taps["lstm0"] = saved["lstm"][0]["y"].detach()[:, :B].cpu()
-    taps["lstm1"] = saved["lstm"][1]["y"].detach()[:, :B].cpu()
+    taps["convo.conv7"] = seq.detach()[:, b0:b0 + B].permute(1, 2, 0).unsqueeze(2).contiguous().cpu()
+    taps["lstm0"] = saved["lstm"][0]["y"].detach()[:, b0:b0 + B].cpu()
+    taps["lstm1"] = saved["lstm"][1]["y"].detach()[:, b0:b0 + B].cpu()
     return force, taps
 
 

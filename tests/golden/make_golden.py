@@ -903,8 +903,106 @@ def make_tracking():
     print("tracking", l32, l64, [len(b[2]) for b in batches], lw.tolist())
 
 
+def _unit_cost_distance(a, b):
+    """python-Levenshtein 0.12.0's `distance` (requirements.txt:70; not installed): classic unit-cost edit distance."""
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def make_tracking_variants():
+    """tests/golden/tracking_f3.npz — SURVEY §8 f3: the NON-decaying weight generators and the sample-wise weighted CTC.
+    LevenshteinWeightGenerator / AttentionWeightGenerator (label_tracking/tracking_methods.py:26-101) are compiled from the
+    reference file with `ast` (the module imports the absent python-Levenshtein: its `distance` is restated as the classic
+    unit-cost edit distance and handed in under the name the class body uses), HistoryAttention is the reference's
+    models/model_attention.py imported unchanged, and tracking_utils.py is the reference's root module: gen_weights ->
+    add_labels_to_history -> generate_ctc_target_batches -> call_crnn -> weighted_ctc_loss with
+    CTCLoss(reduction="none") (train_nn_area.py:147) on the reference CRNN (train-mode BN).  Per method: the weight table,
+    the target batches, and for two image candidates the fp64 loss, log-probs and CRNN gradients; the attention model's
+    state_dict travels with the fixture (it is never optimised: label_tracking/tracking_methods.py:35)."""
+    import abc
+    import types
+    import tracking_utils as rtu
+    from models.model_attention import HistoryAttention
+    src = open(os.path.join(REF, "label_tracking", "tracking_methods.py")).read()
+    tree = ast.parse(src)
+    want = ("LossWeightGenerator", "AttentionWeightGenerator", "LevenshteinWeightGenerator")
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in want]
+    ns = {"torch": torch, "ABCMeta": abc.ABCMeta, "abstractmethod": abc.abstractmethod, "tracking_utils": rtu, "properties": properties,
+          "HistoryAttention": HistoryAttention, "Levenshtein": types.SimpleNamespace(distance=_unit_cost_distance)}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "tracking_methods.py", "exec"), ns)
+    out = {}
+    B, ws, window, keep = 6, 44, 3, 2
+    names = [f"s{i}" for i in range(B)]
+    # histories with agreement (repeated / near-repeated labels) so that the Levenshtein weights are not all zero
+    base = synth_labels(B, 160, 2, 9)
+    near = [w[:-1] + "x" for w in base]
+    hist = [base, near, base]
+    depth = [3, 1, 2, 3, 0, 2]
+    c2i = {c: i for i, c in enumerate(properties.char_set)}
+    current = [base[0], near[1], base[2], synth_labels(1, 171, 1, 9)[0], base[4], near[5]]
+    history = {n: [hist[e][i] for e in range(3)][:depth[i]] for i, n in enumerate(names)}
+    targs = types.SimpleNamespace(window_size=window, query_dim=8, emb_dim=16, attn_activation="sigmoid")
+    torch.manual_seed(1234)
+    gens = {"levenshtein": ns["LevenshteinWeightGenerator"](targs, torch.device("cpu")),
+            "self_attention": ns["AttentionWeightGenerator"](targs, torch.device("cpu"), c2i)}
+    att = gens["self_attention"].attention_model
+    with torch.no_grad():                                        # the reference leaves the positional encodings at zero and never
+        att.positional_encodings.normal_(0, 0.3)                 # trains them; non-zero values exercise the addition
+    for k_, v in att.state_dict().items():
+        out["att|" + k_] = v.numpy().copy()
+    for act in ("softmax", "relu"):                              # the other two activations: weight tables only
+        att.activation = act
+        out[f"weights|self_attention_{act}"] = gens["self_attention"].gen_weights({n: list(v) for n, v in history.items()}, names).detach().numpy()
+    att.activation = "sigmoid"
+
+    def run(method, dt, x):
+        _, crnn = _ref_models(ws, dt)
+        crnn.train()
+        self = types.SimpleNamespace(device=torch.device("cpu"), crnn_model=crnn, char_to_index=c2i, window_size=window,
+                                     weightgen_method=method, primary_loss_fn=torch.nn.CTCLoss(),
+                                     primary_loss_fn_sample_wise=torch.nn.CTCLoss(reduction="none"),
+                                     tracked_labels={n: list(v) for n, v in history.items()})
+        lw = gens[method].gen_weights(self.tracked_labels, names).detach()
+        rtu.add_labels_to_history(self, names, current)
+        batches = rtu.generate_ctc_target_batches(self, names)
+        scores, pred_size = rtu.call_crnn(self, x.to(dt))
+        loss = rtu.weighted_ctc_loss(self, scores, pred_size, batches, lw.to(dt))
+        loss.backward()
+        return crnn, loss.item(), scores.detach(), batches, lw, self.tracked_labels
+
+    for method in ("levenshtein", "self_attention"):
+        k, xs = 0, 5300
+        while k < keep:
+            x = torch.rand(B, 1, 32, 128, generator=torch.Generator().manual_seed(xs))
+            crnn32, l32, _, batches, lw, tracked = run(method, torch.float32, x)
+            crnn64, l64, sc64, _, _, _ = run(method, torch.float64, x)
+            dev = _worst_rel(_grads(crnn32.named_parameters()), _grads(crnn64.named_parameters()), skip=ZERO_GRAD)
+            print("tracking", method, "candidate seed", xs, "fp32 vs fp64", dev, "loss", l64)
+            xs += 1
+            if dev > COND_MAX:
+                continue
+            c = f"{method}|c{k}|"
+            full64(crnn64.named_parameters(), c + "g|", out)
+            out.update({c + "x": x.numpy(), c + "loss32": l32, c + "loss64": l64, c + "lp64": sc64.numpy(), c + "xs": xs - 1})
+            k += 1
+        out["weights|" + method] = lw.numpy()
+        out[f"{method}|n_batches"] = len(batches)
+        for i, (t, ts, idx) in enumerate(batches):
+            out[f"{method}|batch{i}|target"], out[f"{method}|batch{i}|size"], out[f"{method}|batch{i}|idx"] = t.numpy(), ts.numpy(), np.array(idx)
+        print("tracking", method, "weights", lw.tolist())
+    out.update({"window": window, "ws": ws, "names": np.array(names), "current": np.array(current), "n_candidates": keep,
+                "query_dim": targs.query_dim, "emb_dim": targs.emb_dim, "history_json": np.array(json.dumps(history)),
+                "tracked_after_json": np.array(json.dumps(tracked))})
+    np.savez_compressed(os.path.join(HERE, "tracking_f3.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["unet", "crnn", "ctc", "topk", "helpers", "step", "conditioned", "area_step", "tracking", "crop_oversize", "ladder"]
+    which = sys.argv[1:] or ["unet", "crnn", "ctc", "topk", "helpers", "step", "conditioned", "area_step", "tracking", "crop_oversize", "ladder", "tracking_variants"]
     for w in which:
         globals()["make_" + w]()

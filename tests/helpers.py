@@ -204,8 +204,9 @@ def oracle_cond_case(fx, c="", record=False):
     return oracle_cond_phase_b(fx, c, None, record), oracle_cond_phase_a(fx, c, None, record)
 
 
-def oracle_tracking_case(fx, batches, weights, c="c0|", force=None):
-    """weighted_ctc_loss (tracking_utils.py:59-75) on the oracle CRNN (train-mode BN), fp64; force = decisions to impose."""
+def oracle_tracking_case(fx, batches, weights, c="c0|", force=None, sample_wise=False):
+    """weighted_ctc_loss (tracking_utils.py:59-75) on the oracle CRNN (train-mode BN), fp64; force = decisions to impose.
+    sample_wise: the non-decaying branch (:69-73) — per-sample CTC (reduction none) times weights[img_indices, i], mean."""
     import torch.nn.functional as F
     from oracle import model_oracle as mo
     Pc, Bc = mo.split_state(_state64(mo.crnn_state_shapes(), int(fx["ws"]) + 1))
@@ -214,7 +215,11 @@ def oracle_tracking_case(fx, batches, weights, c="c0|", force=None):
     total = 0
     for i, (t, ts, idx) in enumerate(batches):
         ins = torch.full((len(idx),), lp.shape[0], dtype=torch.int)
-        total = total + float(weights[i]) * F.ctc_loss(lp[:, list(idx), :], t, ins, ts)
+        if sample_wise:
+            per = F.ctc_loss(lp[:, list(idx), :], t, ins, ts, reduction="none")
+            total = total + torch.mean(weights[list(idx), i].double() * per)
+        else:
+            total = total + float(weights[i]) * F.ctc_loss(lp[:, list(idx), :], t, ins, ts)
     total.backward()
     return dict(loss=total.item(), lp=lp.detach(), g_crnn={k: p.grad for k, p in Pc.items()})
 
@@ -223,3 +228,21 @@ def full_rel_err(got, ref):
     """plain || got - ref || / || ref || over the FULL tensor (no discard, no conditioning term)."""
     got, ref = got.detach().double().flatten().cpu(), ref.detach().double().flatten().cpu()
     return (got - ref).norm().item() / max(ref.norm().item(), 1e-300)
+
+
+def f3_setup(fx, method, device):
+    """the product's host logic of the non-decaying label-history branch, armed with the fixture's history and (for
+    self_attention) the fixture's HistoryAttention parameters"""
+    import json
+    import types
+    from label_tracking.tracking_methods import weightgenerator_factory
+    names = [str(s) for s in fx["names"]]
+    args = types.SimpleNamespace(window_size=int(fx["window"]), query_dim=int(fx["query_dim"]), emb_dim=int(fx["emb_dim"]),
+                                 attn_activation="sigmoid")
+    wg = weightgenerator_factory(method)(args, device, C2I)
+    if method == "self_attention":
+        wg.attention_model.load_state_dict({k[4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("att|")})
+        wg.attention_model.to(device)
+    self = types.SimpleNamespace(char_to_index=C2I, window_size=int(fx["window"]), weightgen_method=method,
+                                 tracked_labels=json.loads(str(fx["history_json"])), device=device)
+    return names, wg, self

@@ -232,6 +232,44 @@ def test_label_history_ctc_vs_reference():
     print(f"\n[gate] label-history CTC, worst gradient error under the HIP decisions per run: {[(m, i, f'{e:.1e}') for m, i, e in runs]}")
 
 
+@pytest.mark.parametrize("method", ["levenshtein", "self_attention"])
+def test_label_history_variants_vs_reference(method, mfma_mode):
+    """the Levenshtein / self-attention weight generators (label_tracking/tracking_methods.py:26-101,
+    models/model_attention.py:7-38) and the SAMPLE-WISE weighted CTC (tracking_utils.py:69-73, CTCLoss(reduction="none") of
+    train_nn_area.py:147) on the HIP path against tests/golden/tracking_f3.npz, which the reference's own classes produced:
+    weight tables, loss within 1e-4 and log-probs against the reference's fp64 run, every CRNN gradient within 1e-4 of the
+    fp64 oracle under the HIP forward's decisions (the oracle's sample-wise form is pinned to the reference's gradients by
+    tests/test_conditioned_cpu.py::test_tracking_variants_reproduce_reference)."""
+    import decisions as D
+    import tracking_utils as tu
+    from qea.loss import CTCLoss
+    fx = H.golden("tracking_f3.npz")
+    dev = torch.device("cuda")
+    worst = 0.0
+    for ci in range(int(fx["n_candidates"])):
+        c = f"{method}|c{ci}|"
+        names, wg, self = H.f3_setup(fx, method, dev)
+        _, crnn = _hip_models(int(fx["ws"]))
+        crnn.train(); crnn.zero_grad()
+        self.crnn_model, self.primary_loss_fn, self.primary_loss_fn_sample_wise = crnn, CTCLoss(), CTCLoss(reduction="none")
+        w = wg.gen_weights(self.tracked_labels, names)
+        assert np.allclose(w.cpu().numpy(), fx["weights|" + method], rtol=0, atol=1e-6)
+        tu.add_labels_to_history(self, names, [str(s) for s in fx["current"]])
+        batches = tu.generate_ctc_target_batches(self, names)
+        scores, pred_size = tu.call_crnn(self, torch.from_numpy(fx[c + "x"]))
+        force, _ = D.hip_crnn_trace(D.saved_of(scores))
+        loss = tu.weighted_ctc_loss(self, scores, pred_size, batches, w)
+        loss.backward()
+        assert abs(loss.item() - float(fx[c + "loss64"])) <= GATE * float(fx[c + "loss64"])
+        assert (scores.detach().cpu().double() - torch.from_numpy(fx[c + "lp64"])).abs().max().item() < 1e-5
+        r = H.oracle_tracking_case(fx, [(t, ts, idx) for t, ts, idx in batches], w.cpu(), c, force=force, sample_wise=True)
+        errs = {name: H.full_rel_err(p.grad, r["g_crnn"][name]) for name, p in crnn.named_parameters() if name not in ZERO_GRAD}
+        bad = {k: f"{v:.2e}" for k, v in errs.items() if not v <= GATE}
+        assert not bad, (ci, bad)
+        worst = max(worst, max(errs.values()))
+    print(f"\n[gate] label-history CTC, {method} weights, sample-wise loss, mode={mfma_mode}: worst gradient error {worst:.2e}")
+
+
 # ------------------------------------------------------------------------------------------------------------
 def _area_args(tmp, **over):
     from qea.cli_flags import build_parser
@@ -321,7 +359,70 @@ def test_area_trainer_one_minibatch_vs_reference(tmp_path, monkeypatch):
         losses.extend(l.item() for l in out[0])
         return out
     t._replica_losses = spy
+    # --- gradients, not only Adam's signs: what the two optimiser steps are about to consume, and the
+    # decisions of the forward passes that produced it
+    cap = {"fwd": []}
+    import decisions as D
+
+    def watch(mod, tag):
+        orig_fwd = mod.forward
+
+        def fwd(*a, **kw):
+            out = orig_fwd(*a, **kw)
+            if out.requires_grad:
+                cap["fwd"].append((tag, D.saved_of(out), a[0].detach().clone()))
+            return out
+        mod.forward = fwd
+    watch(t.crnn_model, "crnn")
+    watch(t.prep_model, "prep")
+    step_c, step_p = t._step_crnn, t._step_prep
+
+    def spy_step_crnn():
+        (_, sv, xin), = [f for f in cap["fwd"] if f[0] == "crnn"]
+        k_ = xin.shape[0] // inner
+        cap["A"] = dict(g={n: p.grad.detach().clone() for n, p in t.crnn_model.named_parameters()}, x=xin.cpu(),
+                        force=D.hip_crnn_trace(sv, first=k_, start=(inner - 1) * k_)[0])
+        cap["fwd"].clear()
+        step_c()
+        cap["crnn_after_A"] = {n: v.detach().cpu().clone() for n, v in t.crnn_model.state_dict().items()}
+
+    def spy_step_prep(also_crnn=False):
+        fw = {tag: sv for tag, sv, _ in cap["fwd"]}
+        cap["B"] = dict(gp={n: p.grad.detach().clone() for n, p in t.prep_model.named_parameters()},
+                        gc={n: p.grad.detach().clone() for n, p in t.crnn_model.named_parameters()},
+                        force={**D.hip_unet_trace(fw["prep"])[0], **D.hip_crnn_trace(fw["crnn"])[0]})
+        cap["fwd"].clear()
+        step_p(also_crnn)
+    t._step_crnn, t._step_prep = spy_step_crnn, spy_step_prep
     t.train()
+    # ---- the gradient buffers against the fp64 oracle under the HIP decisions (plain 1e-4, full tensors)
+    st64 = lambda sd: {k_: (v.double() if v.is_floating_point() else v.clone()) for k_, v in sd.items()}
+    k_ = len(idx_ref)
+    Pc, Bc = mo.split_state(st64(mo.default_init_state(mo.crnn_state_shapes(), ws + 1)))
+    xa = cap["A"]["x"].double()                                    # the R*k noisy strips the HIP CRNN was given
+    for r in range(inner):                                         # the reference's sequential replica passes (:245-267)
+        xr = xa[r * k_:(r + 1) * k_]
+        if r == inner - 1:
+            lp_r = mo.crnn_forward(Pc, Bc, xr, bn_training=True, trace=mo.Trace(cap["A"]["force"], record=False))
+        else:
+            with torch.no_grad():
+                mo.crnn_forward(Pc, Bc, xr, bn_training=True)
+    ya, ysa = H.encode(sel_rev)
+    F.ctc_loss(lp_r, ya, torch.full((k_,), lp_r.shape[0], dtype=torch.int), ysa).backward()
+    eA = {n: H.full_rel_err(g, Pc[n].grad) for n, g in cap["A"]["g"].items() if n not in ZERO_GRAD}
+    assert max(eA.values()) <= GATE, {n: f"{v:.2e}" for n, v in eA.items() if v > GATE}
+    Pu, Bu = mo.split_state(st64(mo.default_init_state(mo.unet_state_shapes(), ws)))
+    Pc, Bc = mo.split_state(st64(cap["crnn_after_A"]))             # Phase B sees the CRNN Adam just updated
+    trB = mo.Trace(cap["B"]["force"], record=False)
+    img_r = mo.unet_forward(Pu, Bu, torch.from_numpy(fx["x"]).double(), training=True, trace=trB)
+    lp_r = mo.crnn_forward(Pc, Bc, img_r, bn_training=False, trace=trB)
+    yb, ysb = H.encode(labels)
+    (F.ctc_loss(lp_r, yb, torch.full((8,), lp_r.shape[0], dtype=torch.int), ysb) + F.mse_loss(img_r, torch.ones_like(img_r))).backward()
+    eB = {"prep|" + n: H.full_rel_err(g, Pu[n].grad) for n, g in cap["B"]["gp"].items()}
+    eB.update({"crnn|" + n: H.full_rel_err(g, Pc[n].grad) for n, g in cap["B"]["gc"].items()})
+    assert max(eB.values()) <= GATE, {n: f"{v:.2e}" for n, v in eB.items() if v > GATE}
+    print(f"\n[step] TrainNNPrep's gradient buffers vs the fp64 oracle under the HIP decisions: Phase A worst {max(eA.values()):.2e}, "
+          f"Phase B worst {max(eB.values()):.2e}")
     # ---- Phase A: selection, replica losses
     assert sorted(n for n, v in t.selected_samples.items() if v[0]) == sorted(names[i] for i in idx_ref)
     assert np.allclose(losses, fx["A|losses"], rtol=2e-5), (losses, fx["A|losses"])
@@ -437,6 +538,61 @@ def test_replicated_batch_equals_small_batch_oracle(Bfull):
             assert (b.cpu().double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), name
     print(f"\n[replicated] B={Bfull}: worst full-tensor gradient error vs the 8-image fp64 oracle under the HIP decisions "
           f"{max(errs.values()):.2e} ({max(errs, key=errs.get)})")
+
+
+def test_phase_a_at_configs2_size_k103_r4():
+    """BASELINE configs[2]'s Phase-A leg at its real size (train_nn_area.py:245-275 with B = 2048, minibatch_subset_prop 0.95,
+    inner_limit 4): k = 103 picked strips x 4 jitter replicas = 412 rows through ONE CRNN pass with per-replica-group
+    BatchNorm (replica_groups = 4), the backward on the LAST replica's 103 rows only (backward_group = 3) — ragged against every
+    tile size of the kernels (103 = 3 * 32 + 7).  Against the fp64 oracle run as the reference runs it — four sequential
+    train-mode passes, the loss of the last one back-propagated: log-probs of all four groups, running statistics after the four
+    ordered updates, the group-3 gradients at the plain 1e-4 under the HIP forward's decisions, and an input gradient that is
+    exactly zero outside the group."""
+    import decisions as D
+    from oracle import model_oracle as mo
+    from qea.loss import CTCLoss
+    ws, k, R = 90, 103, 4
+    clean = torch.rand(k, 1, 32, 128, generator=torch.Generator().manual_seed(91))
+    noise = torch.randn(R * k, 1, 32, 128, generator=torch.Generator().manual_seed(92)) * 0.05
+    x = (clean.repeat(R, 1, 1, 1) - noise).clamp(0, 1)                       # replica-major, as AddGaussianNoice.batch stacks them
+    labels = H.synth_labels(R * k, 93, 1, 12)
+    ins = torch.full((k,), 31, dtype=torch.int)
+    _, crnn = _hip_models(ws)
+    crnn.train(); crnn.zero_grad()
+    xh = x.cuda().requires_grad_()
+    lp = crnn(xh, replica_groups=R, backward_group=R - 1)
+    force, _ = D.hip_crnn_trace(D.saved_of(lp), first=k, start=(R - 1) * k)
+    y, ysz = H.encode(labels[(R - 1) * k:])
+    loss = CTCLoss()(lp[:, (R - 1) * k:], y, ins, ysz)
+    loss.backward()
+    torch.cuda.synchronize()
+    # the reference's loop: four sequential passes, BN in train mode, the last loss kept (train_nn_area.py:245-271)
+    Pc, Bc = mo.split_state(H._state64(mo.crnn_state_shapes(), ws + 1))
+    lps = []
+    for r in range(R):
+        xr = x[r * k:(r + 1) * k].double()
+        if r == R - 1:
+            xr = xr.requires_grad_()
+            lp_r = mo.crnn_forward(Pc, Bc, xr, bn_training=True, trace=mo.Trace(force, record=False))
+        else:
+            with torch.no_grad():
+                lp_r = mo.crnn_forward(Pc, Bc, xr, bn_training=True)
+        lps.append(lp_r.detach())
+    loss_r = F.ctc_loss(lp_r, y, ins, ysz)
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) <= GATE * abs(loss_r.item())
+    assert (lp.detach().cpu().double() - torch.cat(lps, 1)).abs().max().item() < 1e-5
+    for name, b in crnn.named_buffers():
+        if b.is_floating_point():
+            assert (b.cpu().double() - Bc[name]).abs().max().item() <= 1e-5 * max(1.0, Bc[name].abs().max().item()), name
+        else:
+            assert int(b) == int(Bc[name]) == R, name                         # num_batches_tracked: four updates
+    errs = {name: H.full_rel_err(p.grad, Pc[name].grad) for name, p in crnn.named_parameters() if name not in ZERO_GRAD}
+    errs["dx"] = H.full_rel_err(xh.grad[(R - 1) * k:], xr.grad)
+    bad = {n_: f"{v:.2e}" for n_, v in errs.items() if not v <= GATE}
+    assert not bad, bad
+    assert xh.grad[:(R - 1) * k].abs().max().item() == 0.0
+    print(f"\n[phase A] k = {k} x R = {R}: worst gradient error under the HIP decisions {max(errs.values()):.2e} ({max(errs, key=errs.get)})")
 
 
 def _bn_pixels(name):
