@@ -1140,6 +1140,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         a[2] = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
       };
       bf16x8 ar[2][3];
+#ifdef QEA_HALO_TMPACC
+      f32x16 tq[2];
+#endif
       read_a(0, 0, ar[0]);
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
@@ -1154,12 +1157,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const bool more = f + 1 < STEPS * MI;
           if (more) read_a((f + 1) / MI, (f + 1) % MI, ar[(f + 1) & 1]);
           // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
+#ifdef QEA_HALO_TMPACC
+          // the 16 products of this k-step are summed from ZERO (roundings at the magnitude of one k-step's partial sum) and join
+          // the running sum by ONE round-to-nearest VALU add: the MFMA adder truncates addends it shifts under a dominant C
+          // (tools/micro/mfma_bias.hip: mean -0.003 ulp, rms 0.41 ulp per op) — six such accumulations per k-step into the long
+          // chain were both the random and the pixel-correlated part of the split kernels' error.  The add of row f - 1 is issued
+          // behind the MFMAs of row f (two partial tiles alive), so it never waits for the matrix pipe.
+          const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          f32x16& t = tq[f & 1];
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[cb][0], z16, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][2], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][1], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][0], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][1], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][0], t, 0, 0, 0);
+          // (the empty asm pins each sum at its place in program order: instruction selection otherwise sinks all 144 adds of a
+          // chunk below its last MFMA and spills every partial tile)
+          if (f > 0) {
+            acc[(f - 1) % MI] += tq[(f - 1) & 1];
+            asm volatile("" : "+v"(acc[(f - 1) % MI]));
+          }
+          if (!more) {
+            acc[i] += t;
+            asm volatile("" : "+v"(acc[i]));
+          }
+          if (more) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the three LDS reads of row f + 1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... ahead of the six MFMAs of row f ...
+            __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // ... and the adds of row f - 1 behind them
+          }
+          __builtin_amdgcn_sched_barrier(0);                     // nothing sinks below its row (the adds would pile up as spills)
+          continue;
+#else
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[cb][0], acc[i], 0, 0, 0);
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][2], acc[i], 0, 0, 0);
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][1], acc[i], 0, 0, 0);
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][0], acc[i], 0, 0, 0);
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][1], acc[i], 0, 0, 0);
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][0], acc[i], 0, 0, 0);
+#endif
           if (more) {
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the three LDS reads of row f + 1 ...
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... ahead of the six MFMAs of row f

