@@ -83,3 +83,4 @@ __device__ __forceinline__ float qea_wave_max(float v) {
 bool qea_split_bf16_enabled();
 void qea_prof_begin(int klass, hipStream_t s);
 void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool split_bf16 = false, int tag = 0);
+void qea_prof_abort(int klass);

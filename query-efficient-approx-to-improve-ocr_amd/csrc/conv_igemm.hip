@@ -1491,15 +1491,15 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     QEA_REQUIRE(blocks > 0, "qea_conv_igemm: this launch cannot produce fused statistics (ask qea_conv_igemm_stats_blocks first)");
     a.stats = d->stats;
   }
+  if (tile == 24 && (!halo_bf3_eligible(d) || !d->w_frag_planes)) {
+    qea_set_error("qea_conv_igemm: tile 24 needs Cin = 32 or 64k <= 512, N in {32,64,128k}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate, and w_frag_planes");
+    return QEA_ERR_INVALID;
+  }
   qea_prof_begin(QEA_PROF_CONV_IGEMM, s);
   int rc;
   switch (tile) {
     case 4: rc = launch_halo_any(d, a, s); break;
     case 24:                                               // split-bf16 LDS-halo kernel of the narrow layers: filter in fragment-order planes
-      if (!halo_bf3_eligible(d) || !d->w_frag_planes) {
-        qea_set_error("qea_conv_igemm: tile 24 needs Cin = 32 or 64k <= 512, N in {32,64,128k}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate, and w_frag_planes");
-        return QEA_ERR_INVALID;
-      }
       a.wp = (const char*)d->w_frag_planes;
       rc = launch_halo_bf3_any(d, a, s);
       break;
@@ -1518,9 +1518,12 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 22: rc = p3 ? launch_p3<128, 256, 2, 4>(a, s) : wp3 ? launch_bf3w<128, 256, 2, 4>(a, s) : launch_bf3<128, 256, 2, 4>(a, s); break;
     case 23: rc = p3 ? launch_p3<256, 64, 4, 1>(a, s) : wp3 ? launch_bf3w<256, 64, 4, 1>(a, s) : launch_bf3<256, 64, 4, 1>(a, s); break;
     case 25: rc = p3 ? launch_p3<128, 128, 4, 2>(a, s) : wp3 ? launch_bf3w<128, 128, 4, 2>(a, s) : launch_bf3<128, 128, 4, 2>(a, s); break;  // 8 waves on a 128x128 tile: small grids
-    default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); return QEA_ERR_INVALID;
+    default: qea_set_error("qea_conv_igemm: unknown tile id %d", tile); rc = QEA_ERR_INVALID; break;
   }
-  if (rc != QEA_OK) return rc;
+  if (rc != QEA_OK) {
+    qea_prof_abort(QEA_PROF_CONV_IGEMM);
+    return rc;
+  }
   // algorithmic bytes: input once + filter once + output once
   const double abytes = 4.0 * ((double)d->B * d->H * d->W * d->Cin + (double)d->N * a.K + (double)a.M * d->N);
   // tag = the kernel that ran: QEA_PROF_TAG_CONV(tile, input-channel chunk, output-channel group, fused statistics) for the

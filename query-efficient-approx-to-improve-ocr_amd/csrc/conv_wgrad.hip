@@ -1064,7 +1064,10 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
       hipStream_t hs = (hipStream_t)stream;
       qea_prof_begin(QEA_PROF_CONV_WGRAD, hs);
       rc = launch_halo9(d, h9, hs);
-      if (rc != QEA_OK) return rc;
+      if (rc != QEA_OK) {
+        qea_prof_abort(QEA_PROF_CONV_WGRAD);
+        return rc;
+      }
       reduce_slabs((float*)d->workspace, d->dw, (long long)slab / 4, h9.splits * h9.wk, d->accumulate, hs);
       qea_prof_end(QEA_PROF_CONV_WGRAD, hs, 2.0 * d->B * d->PH * (double)d->PW * (double)slab,
                    4.0 * ((double)d->B * d->PH * d->PW * d->R + (double)d->B * d->QH * d->QW * d->C + (double)slab), true);
@@ -1106,7 +1109,10 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     case 20: launch_bf3<128, 128, 2, 2>(a, s); break;      // split-bf16 forms
     case 21: launch_bf3<128, 64, 2, 2>(a, s); break;
     case 22: launch_bf3<64, 128, 2, 2>(a, s); break;
-    default: qea_set_error("qea_conv_wgrad: unknown tile %d", p.tile); return QEA_ERR_INVALID;
+    default:
+      qea_prof_abort(QEA_PROF_CONV_WGRAD);
+      qea_set_error("qea_conv_wgrad: unknown tile %d", p.tile);
+      return QEA_ERR_INVALID;
   }
   if (p.splits > 1) reduce_slabs((float*)d->workspace, d->dw, a.slab / 4, p.splits, d->accumulate, s);
   qea_prof_end(QEA_PROF_CONV_WGRAD, s, 2.0 * a.M * (double)a.slab,

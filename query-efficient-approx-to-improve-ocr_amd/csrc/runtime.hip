@@ -80,6 +80,14 @@ void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool spl
   pc.open = false;
 }
 
+// an error return between begin and end: the class is closed again, the (re-recordable) start event slot stays unused
+void qea_prof_abort(int klass) {
+  ProfClass& pc = g_prof[klass];
+  if (!pc.on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  pc.open = false;
+}
+
 extern "C" int qea_prof_enable(int klass, int on) {
   QEA_REQUIRE(klass >= 0 && klass < QEA_PROF_NCLASS, "qea_prof_enable: bad class %d", klass);
   g_prof[klass].on = on != 0;

@@ -30,27 +30,40 @@ def pad_to_bucket(img, buckets=BUCKETS):
 class BucketBatchSampler(torch.utils.data.Sampler):
     """Yields index lists whose samples all fall into one width bucket (shuffled within and across buckets)."""
 
-    def __init__(self, widths, batch_size, buckets=BUCKETS, drop_last=True, generator=None):
+    def __init__(self, widths, batch_size, buckets=BUCKETS, drop_last=True, generator=None, seed=0):
+        """generator=None: the sampler draws from its OWN torch.Generator, seeded from (seed, epoch).  Under data parallelism every
+        rank must build the same batch list before dealing it out (qea.dist.deal_batches); the global CPU generator cannot give
+        that, because the ranks consume it by data-dependent amounts in between (CPU jitter of k_r strips, skipped replicas)."""
         self.batch_size, self.drop_last, self.generator = batch_size, drop_last, generator
+        self.seed, self.epoch = int(seed), 0
         self.groups = {}
         for i, w in enumerate(widths):
             self.groups.setdefault(bucket_of(int(w), buckets), []).append(i)
 
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
     def _batches(self):
         out = []
+        gen = self.generator
+        if gen is None:
+            gen = torch.Generator().manual_seed((self.seed * 1000003 + self.epoch) & 0x7FFFFFFF)
         for idx in self.groups.values():
-            perm = torch.randperm(len(idx), generator=self.generator).tolist()
+            perm = torch.randperm(len(idx), generator=gen).tolist()
             for s in range(0, len(idx), self.batch_size):
                 chunk = [idx[j] for j in perm[s:s + self.batch_size]]
                 if len(chunk) == self.batch_size or not self.drop_last:
                     out.append(chunk)
-        order = torch.randperm(len(out), generator=self.generator).tolist()
+        order = torch.randperm(len(out), generator=gen).tolist()
         return [out[i] for i in order]
 
     def __iter__(self):
         from qea import dist as qdist
-        # under torch.distributed every rank draws the same global batch list (identical seeds) and takes every world-th batch
-        return iter(qdist.deal_batches(self._batches()))
+        # under torch.distributed every rank draws the same global batch list (own generator, same seed and epoch) and takes every
+        # world-th batch; the epoch advances per pass so that successive epochs see different batches
+        batches = qdist.deal_batches(self._batches())
+        self.epoch += 1
+        return iter(batches)
 
     def __len__(self):
         from qea import dist as qdist

@@ -26,4 +26,9 @@ class GraphedStep:
 
     def __call__(self):
         self.graph.replay()
+        # a captured FusedAdam writes the weights through raw pointers and runs no Python on replay, so neither the tensors'
+        # _version nor the optimiser's epoch bump moves: every derived weight form cached by an EARLIER eager pass
+        # (qea.ops.weight_cached: dgrad filters, planes, W_hh packs) is stale from here on
+        from . import ops
+        ops.bump_weight_epoch()
         return self.out

@@ -58,6 +58,9 @@ PRESPLIT = {"on": True, "x": False}     # tests / tools: "on" = pre-split filter
 # (raw pointer writes: qea.optim.FusedAdam.step calls bump_weight_epoch()).  With the CRNN frozen in Phase B its derived forms
 # are built once, not once per step (round 1 re-derived 390 filter layouts per step).  Nothing is cached while a hipGraph is
 # being captured: a replay must re-derive from the weights it finds.
+# RULE for any other writer: a write that goes through `p.data` (torch.distributed.broadcast(p.data), p.data.copy_, an EMA) or
+# through a raw pointer moves neither _version nor the epoch — call bump_weight_epoch() after it (qea.graph.GraphedStep does
+# after every replay, TrainerCore after the start-up broadcast, qea.params.FlatState when it re-homes the parameters).
 _wcache = {}
 _wepoch = [0]
 WEIGHT_CACHE = {"on": True}

@@ -116,4 +116,6 @@ def ensure_flat(module):
     if fs is None or not fs.intact() or fs.params[0][1].device != fs.device:
         fs = FlatState(module)
         object.__setattr__(module, "_qea_flat_state", fs)
+        from . import ops
+        ops.bump_weight_epoch()                              # the parameters were re-homed through p.data
     return fs

@@ -120,6 +120,8 @@ class TrainerCore:
             for m in (self.crnn_model, self.prep_model):
                 for t in list(m.parameters()) + list(m.buffers()):
                     torch.distributed.broadcast(t.data, 0)
+            from qea import ops
+            ops.bump_weight_epoch()                              # raw writes through .data: derived weight forms are stale
 
         from label_tracking import tracking_methods
         self.loss_wghts_gnrtr = tracking_methods.weightgenerator_factory(args.weightgen_method)(args, self.device, self.char_to_index)

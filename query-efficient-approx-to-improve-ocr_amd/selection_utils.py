@@ -105,15 +105,15 @@ class TopKCERSampler(DataSampler):
 
     content_free = True     # the pick depends on names / CERs only: a trainer may pick first and clean only the picked images
 
-    def query_global(self, images, labels, num_samples_global, names):
+    def query_global(self, images, labels, num_samples_global, names, with_counts=False):
         """Data-parallel form: the reference ranks the WHOLE minibatch (train_nn_area.py:220-225); here the minibatch is sharded
         over the ranks, so the shards' CERs are all-gathered (qea.dist.global_topk: stable descending order, rank-major index
         as the tie-break = the single-process order of the concatenated minibatch) and each rank keeps the winners that live
-        in its shard — possibly none.  Returns (images_sel, labels_sel, idx, k_global)."""
+        in its shard — possibly none.  Returns (images_sel, labels_sel, idx, k_global[, winners per rank])."""
         from qea import dist as qdist
-        mine, k_global = qdist.global_topk(_known(names, self.cers), num_samples_global)
-        imgs, labs, idx = self._take(images, labels, mine)
-        return imgs, labs, idx, k_global
+        res = qdist.global_topk(_known(names, self.cers), num_samples_global, with_counts=with_counts)
+        imgs, labs, idx = self._take(images, labels, res[0])
+        return (imgs, labs, idx) + tuple(res[1:])
 
 
 class UniformEntropySampler(DataSampler):

@@ -42,6 +42,7 @@ class TrainNNPrep(TrainerCore):
         tr_idx = torch.randperm(len(train_set))[: self.train_subset_size]
         widths = getattr(train_set, "widths", None)
         self.per_shard_topk = bool(getattr(args, "per_shard_topk", False))
+        self.rebalance_topk = not bool(getattr(args, "no_rebalance_topk", False))
         self.select_before_clean = bool(getattr(args, "select_before_clean", False))
         if widths is not None:                                # [new] variable-width lines: one width bucket per batch
             # the bucket batches are formed over the WHOLE (rank-identical) list and dealt round-robin, so every rank
@@ -49,7 +50,8 @@ class TrainNNPrep(TrainerCore):
             from datasets.bucketing import BucketBatchSampler, bucket_collate
             sub = torch.utils.data.Subset(train_set, tr_idx.tolist())
             self.loader_train = torch.utils.data.DataLoader(
-                sub, collate_fn=bucket_collate, batch_sampler=BucketBatchSampler([widths[i] for i in tr_idx.tolist()], self.batch_size))
+                sub, collate_fn=bucket_collate, batch_sampler=BucketBatchSampler([widths[i] for i in tr_idx.tolist()], self.batch_size,
+                                                                                seed=args.random_seed))
         else:
             # data parallel: cut the (identically seeded) permutation to whole global batches, one group of batch_size per rank
             # and step: every rank runs the same number of optimiser steps (a rank with fewer would strand the others in RCCL)
@@ -97,13 +99,16 @@ class TrainNNPrep(TrainerCore):
                 else:
                     img_preds_all = X_var                        # [new] pick on the inputs' names, clean only the picked images below
                 share = 1.0                                      # this rank's weight in the data-parallel mean of Phase A
+                rebalance = False
                 if self.selection_method and epoch >= self.warmup_epochs:
                     if self.world > 1 and not self.per_shard_topk and hasattr(self.sampler, "query_global"):
                         # whole-minibatch TopKCER over the shards (train_nn_area.py:220-225 ranks the whole minibatch); the
                         # averaged gradient equals the global-batch mean when rank r weighs its mean loss by world * n_r / k
                         k = self._num_bb_samples(img_preds_all.shape[0] * self.world)
-                        img_preds, labels_gt, bb_idx, k = self.sampler.query_global(img_preds_all, labels, k, names)
-                        share = self.world * img_preds.shape[0] / max(1, k)
+                        img_preds, labels_gt, bb_idx, k, counts = self.sampler.query_global(img_preds_all, labels, k, names, with_counts=True)
+                        rebalance = self.rebalance_topk and not self.inner_limit_skip    # label histories are keyed by the owner's names
+                        if not rebalance:
+                            share = self.world * img_preds.shape[0] / max(1, k)
                     else:
                         k = self._num_bb_samples(img_preds_all.shape[0])
                         img_preds, labels_gt, bb_idx = self.sampler.query(img_preds_all, labels, k, names)
@@ -112,9 +117,16 @@ class TrainNNPrep(TrainerCore):
                             img_preds = self.prep_model(img_preds.contiguous())
                     img_preds = img_preds.detach()
                     img_preds_names = [names[i] for i in bb_idx.tolist()]
-                    for name in img_preds_names:
+                    for name in img_preds_names:                 # bookkeeping stays with the rank that OWNS the strip
                         if name in self.selected_samples:
                             self.selected_samples[name][epoch] = True
+                    if rebalance:
+                        # [new] the k global winners are dealt out again in equal slices: no rank runs all of Phase A
+                        # while the others wait in the all-reduce.  Phase A needs the cleaned images only (its labels come from
+                        # the black box on the noisy copies), so images are all that travels.
+                        img_preds = qdist.rebalance_rows(img_preds.contiguous(), counts)
+                        img_preds_names = [None] * img_preds.shape[0]
+                        share = self.world * img_preds.shape[0] / max(1, k)
                 else:
                     img_preds, img_preds_names = img_preds_all.detach(), names
                 loss = None

@@ -174,6 +174,97 @@ def test_data_parallel_gloo_world2(tmp_path):
     assert set(r0["picked"]) <= set(r0["shard"]) and set(r1["picked"]) <= set(r1["shard"])
 
 
+def _winners_setup(tmp, tag, batch_size, n=4, **over):
+    from datasets.synthetic import SyntheticTextAreas
+    from ocr_helper.stub_helper import StubHelper
+    from train_nn_area import TrainNNPrep
+    tr_set = SyntheticTextAreas(n, seed=1, include_name=True, include_index=True)
+    cers_path = os.path.join(tmp, f"cers_{tag}.json")
+    json.dump({nm: 0.5 for nm in tr_set.names}, open(cers_path, "w"))
+    args = _args("a", os.path.join(tmp, f"exp_{tag}"), batch_size=batch_size, inner_limit=2, std=0, minibatch_subset="topKCER",
+                 minibatch_subset_prop=0.5, cers_ocr_path=cers_path, **over)
+    t = TrainNNPrep(args, backend=oracle_backend(), train_set=tr_set, val_set=SyntheticTextAreas(batch_size, seed=2, include_name=True), ocr=StubHelper())
+    return t, tr_set
+
+
+def _spy_first_crnn_step(t, rec):
+    """records what the first Adam(CRNN) step consumes — the (all-reduced) gradient; the parameters after the step are not
+    comparable across runs element by element: Adam's first step is +-lr on the SIGN of every gradient element, rounding
+    noise included"""
+    orig = t.optimizer_crnn.step
+
+    def spy(*a, **kw):
+        if "crnn_grad_A" not in rec:
+            rec["crnn_grad_A"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().flatten().clone()
+                                            for p in t.crnn_model.parameters()])
+        return orig(*a, **kw)
+    t.optimizer_crnn.step = spy
+    rl = t._replica_losses
+
+    def spy_rl(imgs, noiser, R, **kw):
+        rec.setdefault("phase_a_images", []).append(imgs.detach().clone())
+        return rl(imgs, noiser, R, **kw)
+    t._replica_losses = spy_rl
+
+
+def _dp_winners_worker(rank, world, port, tmp, rebalance):
+    """2 ranks x batch 2 = one global minibatch of 4, k = 2, and BOTH global winners live in rank 0's shard."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "query-efficient-approx-to-improve-ocr_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    from qea import dist as qdist
+    t, tr_set = _winners_setup(tmp, f"r{rank}_{int(rebalance)}", 2, no_rebalance_topk=not rebalance)
+    shard = [tr_set.names[i] for i in t.loader_train.sampler]
+    shards = [None] * world
+    dist.all_gather_object(shards, shard)
+    for r, names in enumerate(shards):                        # the same table on every rank: rank 0's strips carry the two worst CERs
+        for j, nm in enumerate(names):
+            t.sampler.cers[nm] = (0.9 - 0.1 * j) if r == 0 else (0.2 - 0.1 * j)
+    rec = {"shards": shards}
+    _spy_first_crnn_step(t, rec)
+    t.train()
+    rec["flat"] = torch.cat([p.detach().flatten() for p in t.prep_model.parameters()] + [p.detach().flatten() for p in t.crnn_model.parameters()])
+    rec["picked"] = sorted(nm for nm, v in t.selected_samples.items() if v[0])
+    torch.save(rec, os.path.join(tmp, f"win_r{rank}_{int(rebalance)}.pt"))
+    dist.destroy_process_group()
+
+
+def test_all_global_winners_on_one_rank(tmp_path):
+    """VERDICT r2 #8 / SURVEY §8e.  (a) winners processed where they live (--no_rebalance_topk): rank 0 runs the whole of Phase A,
+    rank 1 joins the all-reduce with a zero gradient, and the gradient Adam(CRNN) consumes equals the SINGLE-PROCESS gradient on
+    the concatenated minibatch.  (b) default: the winners are dealt out again in equal slices — rank 1 processes rank 0's second
+    winner, the ranks stay in lock-step, and the bookkeeping (selected_samples) stays with the owner."""
+    tmp = str(tmp_path)
+    port = 31500 + os.getpid() % 2000
+    for rebalance in (False, True):
+        mp.start_processes(_dp_winners_worker, args=(2, port + int(rebalance), tmp, rebalance), nprocs=2, join=True, start_method="spawn")
+    a0, a1 = torch.load(tmp_path / "win_r0_0.pt"), torch.load(tmp_path / "win_r1_0.pt")
+    b0, b1 = torch.load(tmp_path / "win_r0_1.pt"), torch.load(tmp_path / "win_r1_1.pt")
+    for r0, r1 in ((a0, a1), (b0, b1)):
+        assert torch.equal(r0["flat"], r1["flat"])                               # lock-step after both updates
+        assert r0["picked"] == sorted(r0["shards"][0]) and r1["picked"] == []    # both winners are rank 0's; bookkeeping with the owner
+    assert [x.shape[0] for x in a0["phase_a_images"]] == [2] and "phase_a_images" not in a1    # (a) rank 1 had no Phase-A work
+    assert [x.shape[0] for x in b0["phase_a_images"]] == [1] and [x.shape[0] for x in b1["phase_a_images"]] == [1]   # (b) one winner each
+    # (b) what travelled: rank 0's winners in rank-major order = its descending-CER order; rank 1 got the second one, bit for bit
+    assert torch.equal(b0["phase_a_images"][0][0], a0["phase_a_images"][0][0]) and torch.equal(b1["phase_a_images"][0][0], a0["phase_a_images"][0][1])
+    # (a) == the single-process update: one process, the four strips as ONE minibatch, the same CER table
+    t, tr_set = _winners_setup(tmp, "single", 4)
+    assert t.world == 1
+    for r, names in enumerate(a0["shards"]):
+        for j, nm in enumerate(names):
+            t.sampler.cers[nm] = (0.9 - 0.1 * j) if r == 0 else (0.2 - 0.1 * j)
+    rec = {}
+    _spy_first_crnn_step(t, rec)
+    t.train()
+    assert sorted(nm for nm, v in t.selected_samples.items() if v[0]) == a0["picked"]
+    g1, g2 = rec["crnn_grad_A"].double(), a0["crnn_grad_A"].double()
+    assert (g1 - g2).norm().item() <= 1e-5 * g1.norm().item(), ((g1 - g2).norm() / g1.norm()).item()
+    assert torch.equal(a0["crnn_grad_A"], a1["crnn_grad_A"])                     # the zero-gradient rank received the same mean
+
+
 def test_equal_shards_give_every_rank_the_same_step_count(monkeypatch):
     """qea.dist.equal_shards / deal_batches: any dataset size, any world size -> identical step counts, disjoint shards."""
     from qea import dist as qdist

@@ -159,3 +159,48 @@ def test_hipgraph_replay_of_a_phase_b_step_equals_eager():
     assert torch.isfinite(loss_g).all() and torch.equal(loss_g, loss_e)
     for (k, a), (_, b) in zip(prep_e.state_dict().items(), prep_g.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_eager_forward_after_graph_replays_sees_the_new_weights():
+    """a replayed hipGraph updates the weights through raw pointers and runs no Python, so nothing moved the
+    weight-cache key (qea.ops.weight_cached) — an eager forward AFTER replays used the derived filter planes of the weights
+    BEFORE them.  Sequence: eager eval forward (cache filled) -> replays -> eager eval forward, against the same forward with
+    the cache off."""
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea import ops
+    from qea.graph import GraphedStep
+    from qea.optim import FusedAdam
+    B = 8
+    x = H.synth_images(B, 15).cuda()
+    ones = torch.ones(B, 1, 32, 128, device="cuda")
+    prep = UNet()
+    prep.load_state_dict(mo.seeded_state(mo.unet_state_shapes(), 3))
+    prep = prep.cuda()
+    opt = FusedAdam(prep.parameters(), lr=1e-3, capturable=True)
+
+    def step():
+        prep.train()
+        prep.zero_grad()
+        loss = torch.nn.functional.mse_loss(prep(x), ones)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def eval_forward():
+        prep.eval()
+        with torch.no_grad():
+            return prep(x).clone()
+    g = GraphedStep(step, warmup=1)
+    before = eval_forward()                                   # fills the cache with the forms of the CURRENT weights
+    for _ in range(3):
+        g()
+    torch.cuda.synchronize()
+    cached = eval_forward()
+    ops.WEIGHT_CACHE["on"] = False
+    try:
+        fresh = eval_forward()
+    finally:
+        ops.WEIGHT_CACHE["on"] = True
+    assert not torch.equal(before, fresh)                     # the replays did move the weights
+    assert torch.equal(cached, fresh)
