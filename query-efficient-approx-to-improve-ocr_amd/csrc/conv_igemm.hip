@@ -1003,12 +1003,21 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // CIN is the channel CHUNK held in LDS at a time (32, or 64 for every wider input: `chunks` = C_in / 64 passes over the same
 // pixel tile, the next chunk's halo gathered into registers under this chunk's MFMAs); COUT in {32, 64, 128}.
-template <int CIN, int COUT, int TH, bool STATS>
+// IMW = 0: the tile is a TH x 32 window of ONE image (W % 32 == 0, H % TH == 0).  IMW = 16 or 8: SMALL IMAGES — the image is IMW
+// pixels wide and IMH = IMW / 4 high (UNet levels 4 and 5 of a 32x128 strip: 4x16 and 2x8), and a tile holds 32 / IMW images side
+// by side and TH / IMH on top of each other, every image with its own zero columns left and right; rows above / below an image
+// are all zero, so ONE shared zero row (stored row TH) stands for them (the row a tap reads is a compile-time function of (row,
+// kh)).  These levels used to run in the generic implicit-GEMM tile, which gathers and splits every input element once per tap.
+template <int CIN, int COUT, int TH, bool STATS, int IMW = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
                                                                int Ntot, const float* __restrict__ mask, int ldmask, int total) {
-  constexpr int TW = 32, HW_ = TW + 2, HH = TH + 2, HP = HH * HW_;
+  constexpr bool SMALL = IMW != 0;
+  constexpr int IMH = SMALL ? IMW / 4 : 1;               // image height in small-image mode
+  constexpr int IPX = SMALL ? 32 / IMW : 1, IPY = SMALL ? TH / IMH : 1;   // images per tile, across and down
+  constexpr int TW = 32, HW_ = SMALL ? IPX * (IMW + 2) : TW + 2, HH = SMALL ? TH + 1 : TH + 2, HP = HH * HW_;
+  static_assert(!SMALL || (TH % IMH == 0 && COUT == 128), "small-image tiles: whole images per tile, one wave row");
   constexpr int WN = COUT / 32, WM = 4 / WN;            // waves across output channels / across tile rows
   constexpr int MI = TH / WM;                           // 32-pixel rows per wave
   constexpr int KS = CIN / 16;                          // 16-channel MFMA k-steps per tap
@@ -1031,6 +1040,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     Item it;
     it.nb = lid % nblk;
     it.tile_id = lid / nblk;
+    if (SMALL) {                                          // tile_id = group of IPX * IPY consecutive images
+      it.b = it.tile_id * (IPX * IPY);
+      it.x0 = it.y0 = 0;
+      return it;
+    }
     int bid = it.tile_id;
     const int tx = bid % tiles_x;
     bid /= tiles_x;
@@ -1057,8 +1071,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int hy = q / HW_, hx = q - hy * HW_;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int iy = it.y0 + hy - 1, ix = it.x0 + hx - 1;
-      const bool ok = q < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      int iy, ix;
+      bool ok;
+      if (SMALL) {                                        // stored row hy < TH = image row hy % IMH of image row-group hy / IMH; row TH = zeros
+        const int gx = hx / (IMW + 2);
+        const int img = (hy / IMH) * IPX + gx;
+        ix = hx - gx * (IMW + 2) - 1;
+        iy = (img * IMH + hy % IMH);                      // rows of consecutive images are consecutive in memory (W == IMW, H == IMH)
+        ok = q < HP && hy < TH && (unsigned)ix < (unsigned)IMW && it.b + img < B;
+      } else {
+        iy = it.y0 + hy - 1;
+        ix = it.x0 + hx - 1;
+        ok = q < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      }
       const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)iy * W + ix) * ldx : x);
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       hv[i] = ok ? v : zero;
@@ -1133,7 +1158,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       auto read_a = [&](int st, int i, bf16x8* a) {
         const int tap = st / KS, cs = st % KS;
         const int kh = tap / 3, kw = tap % 3;
-        const int hp = (wm * MI + i + kh) * HW_ + fr + kw;
+        int hp;
+        if (SMALL) {                                      // WM == 1: the tile row is i (compile time), so is the stored row of tap kh
+          const int rr = i % IMH + kh - 1;
+          const int srow = (rr >= 0 && rr < IMH) ? (i / IMH) * IMH + rr : TH;
+          hp = srow * HW_ + fr + 2 * (fr / IMW) + kw;     // lane's pixel x = fr: image fr / IMW, its columns start after the zero column
+        } else {
+          hp = (wm * MI + i + kh) * HW_ + fr + kw;
+        }
         const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
         a[0] = *reinterpret_cast<const bf16x8*>(src);
         a[1] = *reinterpret_cast<const bf16x8*>(src + PLANE);
@@ -1215,20 +1247,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double st0 = 0.0, st1 = 0.0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      float* yrow = y + ((size_t)(cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0) * ldy;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        size_t prow;                                    // pixel index of (tile row wm * MI + i, tile column px) in the [B*H*W] row space
+        bool live = true;
+        if (SMALL) {
+          const int img = (i / IMH) * IPX + px / IMW;
+          prow = ((size_t)(cur.b + img) * IMH + i % IMH) * IMW + px % IMW;
+          live = cur.b + img < B;                       // the last tile of an image count that is no multiple of IPX * IPY
+        } else {
+          prow = (size_t)(cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0 + px;
+        }
         float v = acc[i][r];
         if (scale && bias) v = __fmaf_rn(v, esc, ebi);
         else if (scale) v *= esc;
         else if (bias) v += ebi;
         if (relu) v = fmaxf(v, 0.f);
-        if (mask) {                                     // ReLU mask of another tensor (input gradient through a bare ReLU)
-          const size_t mrow = (size_t)(cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0 + px;
-          v = (mask[mrow * ldmask + n] > 0.f) ? v : 0.f;
-        }
-        yrow[(size_t)px * ldy + n] = v;
+        if (!live) continue;
+        if (mask) v = (mask[prow * ldmask + n] > 0.f) ? v : 0.f;   // ReLU mask of another tensor (input gradient through a bare ReLU)
+        y[prow * ldy + n] = v;
         if (STATS) {
           st0 += (double)v;
           st1 += (double)v * (double)v;
@@ -1281,16 +1319,17 @@ __global__ void pack_frag_planes_kernel(const float* __restrict__ w, __bf16* __r
   for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + ((((size_t)gst * 3 + p) * WNr + nj) * 64 + lane) * 8) = pl[p];
 }
 
-template <int CIN, int COUT, int TH, bool STATS>
+template <int CIN, int COUT, int TH, bool STATS, int IMW = 0>
 int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
-  constexpr size_t lds = (size_t)3 * (TH + 2) * 34 * CIN * 2;
-  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS>;
+  constexpr size_t lds = IMW ? (size_t)3 * (TH + 1) * (32 / IMW) * (IMW + 2) * CIN * 2 : (size_t)3 * (TH + 2) * 34 * CIN * 2;
+  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS, IMW>;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr_rc != (int)hipSuccess) {
     qea_set_error("qea_conv_igemm(halo bf3): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
     return QEA_ERR_LAUNCH;
   }
-  const long long total = (long long)a.B * (a.H / TH) * (a.W / 32) * (a.N / COUT);
+  const long long total = IMW ? (long long)qea_cdiv(a.B, (32 / IMW) * (TH / (IMW / 4))) * (a.N / COUT)
+                              : (long long)a.B * (a.H / TH) * (a.W / 32) * (a.N / COUT);
   if (total <= 0 || total > 0x7fffffffLL) {
     qea_set_error("qea_conv_igemm(halo bf3): grid %lld out of range", total);
     return QEA_ERR_INVALID;
@@ -1310,9 +1349,9 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
   return QEA_OK;
 }
 
-template <int CIN, int COUT, int TH>
+template <int CIN, int COUT, int TH, int IMW = 0>
 int launch_halo_bf3(const ConvArgs& a, hipStream_t s) {
-  return a.stats ? launch_halo_bf3_<CIN, COUT, TH, true>(a, s) : launch_halo_bf3_<CIN, COUT, TH, false>(a, s);
+  return a.stats ? launch_halo_bf3_<CIN, COUT, TH, true, IMW>(a, s) : launch_halo_bf3_<CIN, COUT, TH, false, IMW>(a, s);
 }
 
 bool halo_eligible(const qea_conv_desc* d) {
@@ -1323,15 +1362,34 @@ bool halo_eligible(const qea_conv_desc* d) {
 }
 
 // the split-bf16 LDS-halo kernel takes C_in = 32 or a multiple of 64 (up to 256) and C_out in {32, 64, 128}
+// small-image tiles (several whole images per 4 x 32 tile): 4x16 and 2x8 images, C_in a multiple of 64, C_out a multiple of 128
+int halo_bf3_small(const qea_conv_desc* d) {
+  if (d->Cin % 64 || d->Cin > 512 || d->N % 128) return 0;
+  if (d->W == 16 && d->H == 4) return 16;
+  if (d->W == 8 && d->H == 2) return 8;
+  return 0;
+}
+
 bool halo_bf3_eligible(const qea_conv_desc* d) {
   const bool cin = d->Cin == 32 || (d->Cin % 64 == 0 && d->Cin <= 512);
   const bool cout = d->N == 32 || d->N == 64 || d->N % 128 == 0;
   const int th = d->Cin == 32 ? 8 : 4;
+  const bool shape = (d->W % 32 == 0 && d->H % th == 0) || halo_bf3_small(d) != 0;
   return cin && cout && d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->OH == d->H &&
-         d->OW == d->W && d->W % 32 == 0 && d->H % th == 0 && d->out_mode == QEA_OUT_NHWC && !d->accumulate;
+         d->OW == d->W && shape && d->out_mode == QEA_OUT_NHWC && !d->accumulate;
+}
+
+// pixel tiles of a launch on the split-bf16 LDS-halo kernel (each leaves halo_bf3_wm() rows of fused BatchNorm partials)
+long long halo_bf3_tiles(const qea_conv_desc* d) {
+  const int sm = halo_bf3_small(d);
+  if (sm) return qea_cdiv(d->B, (32 / sm) * (4 / (sm / 4)));
+  return (long long)d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32);
 }
 
 int launch_halo_bf3_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  const int sm = halo_bf3_small(d);
+  if (sm == 16) return launch_halo_bf3<64, 128, 4, 16>(a, s);
+  if (sm == 8) return launch_halo_bf3<64, 128, 4, 8>(a, s);
   if (d->Cin == 32) {
     if (d->N == 32) return launch_halo_bf3<32, 32, 8>(a, s);
     if (d->N == 64) return launch_halo_bf3<32, 64, 8>(a, s);
@@ -1414,7 +1472,7 @@ int resolve_tile(const qea_conv_desc* d, const ConvArgs& a) {
 int stats_blocks_for(const qea_conv_desc* d, const ConvArgs& a, int tile, bool wp3) {
   if (d->scale || d->bias || d->mask || d->relu || d->accumulate || d->out_mode != QEA_OUT_NHWC) return 0;
   if (tile == 4 && halo_eligible(d)) return d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32) * 4;
-  if (tile == 24 && halo_bf3_eligible(d)) return d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32) * halo_bf3_wm(d);
+  if (tile == 24 && halo_bf3_eligible(d)) return (int)halo_bf3_tiles(d) * halo_bf3_wm(d);
   if (!wp3) return 0;
   switch (tile) {
     case 21: return qea_cdiv(a.M, 256) * 4;
@@ -1492,7 +1550,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     a.stats = d->stats;
   }
   if (tile == 24 && (!halo_bf3_eligible(d) || !d->w_frag_planes)) {
-    qea_set_error("qea_conv_igemm: tile 24 needs Cin = 32 or 64k <= 512, N in {32,64,128k}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate, and w_frag_planes");
+    qea_set_error("qea_conv_igemm: tile 24 needs Cin = 32 or 64k <= 512, N in {32,64,128k}, 3x3 pad 1 stride 1, W %% 32 == 0 (or 4x16 / 2x8 images with Cin = 64k, N = 128k), no accumulate, and w_frag_planes");
     return QEA_ERR_INVALID;
   }
   qea_prof_begin(QEA_PROF_CONV_IGEMM, s);
@@ -1528,7 +1586,8 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   const double abytes = 4.0 * ((double)d->B * d->H * d->W * d->Cin + (double)d->N * a.K + (double)a.M * d->N);
   // tag = the kernel that ran: QEA_PROF_TAG_CONV(tile, input-channel chunk, output-channel group, fused statistics) for the
   // LDS-halo split kernel (its template instantiation), the tile id otherwise
-  const int tag = tile == 24 ? QEA_PROF_TAG_HALO_BF3(d->Cin == 32 ? 32 : 64, d->N > 128 ? 128 : d->N, a.stats != nullptr) : tile;
+  // (the small-image instantiations of the halo kernel are their own kernels in a trace: + 20 * image width)
+  const int tag = tile == 24 ? QEA_PROF_TAG_HALO_BF3(d->Cin == 32 ? 32 : 64, d->N > 128 ? 128 : d->N, a.stats != nullptr) + 20 * halo_bf3_small(d) : tile;
   qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20, tag);
   QEA_CHECK_LAUNCH();
   return QEA_OK;

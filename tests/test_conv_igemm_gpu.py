@@ -245,7 +245,11 @@ def test_fused_bn_statistics_epilogue(shape):
 
 @pytest.mark.parametrize("Cin,Cout,H,W,B", [(32, 32, 8, 32, 3), (32, 64, 16, 64, 2), (64, 32, 4, 32, 5), (64, 64, 12, 96, 2), (32, 32, 32, 128, 2),
                                             (64, 64, 16, 64, 3), (128, 64, 16, 64, 2), (64, 128, 8, 32, 3), (128, 128, 8, 32, 2), (256, 128, 4, 32, 3),
-                                            (32, 128, 8, 64, 2), (192, 32, 4, 32, 2), (256, 256, 8, 32, 2), (512, 512, 4, 32, 2), (128, 384, 4, 32, 3)])
+                                            (32, 128, 8, 64, 2), (192, 32, 4, 32, 2), (256, 256, 8, 32, 2), (512, 512, 4, 32, 2), (128, 384, 4, 32, 3),
+                                            # small-image tiles: 4x16 images two per tile, 2x8 images eight per tile; image counts that
+                                            # leave the last tile partly empty (UNet levels 4 and 5, models/model_unet.py:19-29)
+                                            (128, 256, 4, 16, 3), (256, 256, 4, 16, 4), (512, 256, 4, 16, 5), (64, 128, 4, 16, 2),
+                                            (256, 512, 2, 8, 8), (512, 512, 2, 8, 11), (64, 128, 2, 8, 3), (128, 128, 2, 8, 17)])
 def test_narrow_split_bf16_halo_kernel(Cin, Cout, H, W, B):
     """tile 24 = conv3x3_halo_bf3_kernel (input halo split ONCE into bf16 planes in LDS, filter in fragment-order planes): against
     fp64, against the fp32 LDS-halo kernel (tile 4), reading from / writing into wider (concat) buffers, with the fused
