@@ -203,8 +203,10 @@ class CRNNEngine:
                         dg = gates[:, :, d * 4 * HID:]
                         ops.conv_wgrad(dg, xin, G[f"lstm.weight_ih_l{layer}{suf}"], B=1, PH=1, PW=TB, QH=1, QW=TB, R=4 * HID, Cc=512,
                                        KH=1, KW=1, ldp=8 * HID, ldq=512, accumulate=True)
-                        ops.colsum(dg, 8 * HID, TB, 4 * HID, G[f"lstm.bias_ih_l{layer}{suf}"], accumulate=True)
-                        ops.colsum(dg, 8 * HID, TB, 4 * HID, G[f"lstm.bias_hh_l{layer}{suf}"], accumulate=True)
+                        db = torch.empty(4 * HID, device=dev)                  # b_ih and b_hh enter the gates as a sum: one column
+                        ops.colsum(dg, 8 * HID, TB, 4 * HID, db)               # sum (a full pass over the gate gradients) serves both
+                        G[f"lstm.bias_ih_l{layer}{suf}"].add_(db)
+                        G[f"lstm.bias_hh_l{layer}{suf}"].add_(db)
                         if T > 1:
                             n = (T - 1) * B
                             if d == 0:
