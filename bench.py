@@ -149,7 +149,7 @@ def cpu_baseline():
             "b128": b128, "b32": b32, "host": host}
 
 
-DOMINANT_KERNEL = "conv3x3_halo_bf3_kernel<64, 128, 4, false>"
+DOMINANT_KERNEL = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0>"
 
 
 def source_hash():
@@ -448,16 +448,16 @@ def main():
 
     traffic, traffic_dom, traffic_note = None, None, "no PMC profile for this build"
     try:                                             # HBM bytes per launch of the dominant class, from the committed PMC pass of THIS build
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
         if pm.get("source_hash") != source_hash():
-            traffic_note = f"profiles/r02_pmc_traffic.json was taken on sources {pm.get('source_hash')} != this build {source_hash()}: refused"
+            traffic_note = f"profiles/r03_pmc_traffic.json was taken on sources {pm.get('source_hash')} != this build {source_hash()}: refused"
         elif pm.get("batch_per_gpu") != B or pm.get("full_step") != (not args.phase_b_only):
-            traffic_note = "profiles/r02_pmc_traffic.json was taken on another workload: refused"
+            traffic_note = "profiles/r03_pmc_traffic.json was taken on another workload: refused"
         else:
             traffic = pm["conv_igemm"]["hbm_bytes_per_launch"]
             kt = pm.get("per_kernel_bytes_per_launch", {}).get(DOMINANT_KERNEL)
             traffic_dom = kt["fetch"] + kt["write"] if kt else None
-            traffic_note = "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE in separate passes, profiles/r02_pmc_traffic.json (same sources)"
+            traffic_note = "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE in separate passes, profiles/r03_pmc_traffic.json (same sources)"
     except (OSError, KeyError, ValueError):
         pass
 
@@ -516,7 +516,7 @@ def main():
                          "traffic": traffic_dom, "traffic_note": traffic_note, "source_hash": source_hash(),
                          "measured": "HIP events around every launch of this kernel over the same K steps re-run with the wgrad side stream "
                                      f"disabled ({dt_serial / args.steps * 1e3:.2f} ms/step single-stream vs {dt / args.steps * 1e3:.2f} overlapped); "
-                                     "avg_launch_us is comparable with profiles/r02_kernel_stats_b2048_single_stream.csv",
+                                     "avg_launch_us is comparable with profiles/r03_kernel_stats_b2048_single_stream.csv",
                          "peak_is": f"bf16 dense MFMA peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} TFLOP/s fp32-equivalent",
                          "launch_class": {
                              "what": "all qea_conv_igemm launches (implicit-GEMM conv fwd/dgrad, convT, LSTM/linear GEMMs): the LDS-halo kernel above, "
