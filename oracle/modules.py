@@ -39,9 +39,15 @@ class OracleUNet(_Tree):
         super().__init__()
         self._populate(mo.seeded_state(mo.unet_state_shapes(in_channels, out_channels, init_features), seed))
 
-    def forward(self, x):
+    def forward(self, x, bn_groups=1):
+        """bn_groups = N: the SPECIFICATION of the product's fused form — N sequential passes over the N groups (one document
+        per call, train_nn_patch.py:318-321), outputs concatenated."""
+        import torch
         P, Bf = self._state()
-        return mo.unet_forward(P, Bf, x, training=self.training)
+        if bn_groups <= 1 or not self.training:
+            return mo.unet_forward(P, Bf, x, training=self.training)
+        k = x.shape[0] // bn_groups
+        return torch.cat([mo.unet_forward(P, Bf, x[g * k:(g + 1) * k], training=True) for g in range(bn_groups)])
 
 
 class OracleCRNN(_Tree):

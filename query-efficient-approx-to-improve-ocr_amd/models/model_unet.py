@@ -64,7 +64,10 @@ class UNet(nn.Module):
             raise QeaError("UNet: mixed BatchNorm train/eval modes are not supported")
         return modes.pop()
 
-    def forward(self, x):
+    def forward(self, x, bn_groups=1):
+        """x [B,1,H,W] -> [B,1,H,W].  bn_groups = N (new, additive; train mode only): x holds N equal groups of images stacked
+        along the batch (N documents of the patch flow); batch-statistic BatchNorm runs per group and the running statistics
+        are updated once per group in order, so one call equals N sequential calls of the reference on the N groups."""
         _require_cuda(x, "UNet")
         eng = self._engine()
         ensure_flat(self)
@@ -73,7 +76,7 @@ class UNet(nn.Module):
             anchor = torch.zeros((), device=x.device, requires_grad=True)
             self.__dict__["_qea_anchor"] = anchor
         wants = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        return UNetFn.apply(x, anchor if wants else None, eng, self._bn_mode())
+        return UNetFn.apply(x, anchor if wants else None, eng, self._bn_mode(), int(bn_groups))
 
     def zero_grad(self, set_to_none=True):
         fs = self.__dict__.get("_qea_flat_state")

@@ -17,8 +17,8 @@ def _require_cuda(t, who):
 
 class UNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, engine, training):
-        out, saved = engine.forward(x.contiguous(), training, need_grad=bool(ctx.needs_input_grad[1]))
+    def forward(ctx, x, anchor, engine, training, groups=1):
+        out, saved = engine.forward(x.contiguous(), training, need_grad=bool(ctx.needs_input_grad[1]), groups=groups)
         ctx.engine, ctx.saved = engine, saved
         return out
 
@@ -28,7 +28,7 @@ class UNetFn(torch.autograd.Function):
             raise QeaError("UNet backward called without saved activations")
         ctx.engine.backward(ctx.saved, dout)
         ctx.saved = None
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class CRNNFn(torch.autograd.Function):

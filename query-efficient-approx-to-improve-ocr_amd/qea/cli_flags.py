@@ -52,6 +52,10 @@ FLAGS = [
                                                              "makes every image's output independent of the rest of the minibatch)"), "a"),
     ("--per_shard_topk", dict(action="store_true", help="[new] data-parallel runs only: pick the TopKCER subset per GPU shard instead of "
                                                         "over the whole minibatch (not the reference's selection; saves one 32 KB all-gather)"), "a"),
+    ("--docs_per_step", dict(type=int, default=1, help="[new] documents per optimiser step (the reference hard-codes one, train_nn_patch.py:37). "
+                                                      "The N documents go through the cleaner as ONE batch with per-document BatchNorm statistics "
+                                                      "and through the CRNN of Phase B as one batch; forward values equal N sequential passes, the "
+                                                      "gradients of the N documents accumulate into one Adam step"), "p"),
     ("--no_rebalance_topk", dict(action="store_true", help="[new] data-parallel runs only: process every global TopKCER winner on the rank "
                                                            "that owns it instead of dealing the winners out in equal slices (one all-reduce of "
                                                            "k x 16 KB images); always so with --inner_limit_skip (label histories stay with the owner)"), "a"),

@@ -50,8 +50,11 @@ class UNetEngine:
         Bf = dict(self.m.named_buffers())
         return P, Bf
 
-    def _conv_bn_relu(self, P, Bf, blk, i, x, ldx, cin, B, H, W, out, ldo, training, saved):
-        """x [B,H,W,cin] (pixel stride ldx) -> conv -> BN -> ReLU -> out (pixel stride ldo)."""
+    def _conv_bn_relu(self, P, Bf, blk, i, x, ldx, cin, B, H, W, out, ldo, training, saved, groups=1):
+        """x [B,H,W,cin] (pixel stride ldx) -> conv -> BN -> ReLU -> out (pixel stride ldo).
+        groups > 1 (train mode): batch statistics per group of B / groups consecutive images, running statistics updated once
+        per group in order — what `groups` sequential forward calls of the reference do (one document per call,
+        train_nn_patch.py:318-321)."""
         dev = x.device
         cout = blk.cout
         M = B * H * W
@@ -71,12 +74,25 @@ class UNetEngine:
             ops.conv_c1_fwd(x, w, None, y, cout, B, H, W, cout, relu=False)
         else:
             # train-mode BatchNorm: the conv's epilogue also leaves per-block fp64 column sums of y (no second pass over y)
+            # (per-group statistics take the separate pass: a statistics block of the generic tile may straddle two images)
             fused = ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=cout,
-                                   w_src=("fwd", w), want_stats=training)
-        coef = torch.empty(4, cout, device=dev)  # mean, invstd, scale, shift
-        stat64 = None
+                                   w_src=("fwd", w), want_stats=training and groups == 1)
         gamma, beta = P[blk.key(i, "gamma")], P[blk.key(i, "beta")]
         rm, rv = Bf[blk.key(i, "rm")], Bf[blk.key(i, "rv")]
+        if training and groups > 1:
+            Mg = M // groups
+            coef = torch.empty(groups, 4, cout, device=dev)
+            stat64 = torch.empty(groups, 2, cout, device=dev, dtype=torch.float64) if saved is not None else None
+            for g in range(groups):
+                yg = y[g * Mg:(g + 1) * Mg]
+                ops.bn_train_stats(yg, cout, Mg, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[g, 0], coef[g, 1], coef[g, 2], coef[g, 3],
+                                   stat64[g] if stat64 is not None else None)
+                ops.bn_apply(yg, cout, out[g * Mg:(g + 1) * Mg], ldo, Mg, cout, coef[g, 2], coef[g, 3], relu=True)
+            if saved is not None:
+                saved.append((y, coef, stat64))
+            return
+        coef = torch.empty(4, cout, device=dev)  # mean, invstd, scale, shift
+        stat64 = None
         if training:
             stat64 = torch.empty(2, cout, device=dev, dtype=torch.float64) if saved is not None else None
             if fused is not None:
@@ -91,8 +107,8 @@ class UNetEngine:
             saved.append((y, coef, stat64))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, training, need_grad):
-        """x: [B,1,H,W] contiguous CUDA fp32.  Returns (out [B,1,H,W], ctx or None)."""
+    def forward(self, x, training, need_grad, groups=1):
+        """x: [B,1,H,W] contiguous CUDA fp32.  Returns (out [B,1,H,W], ctx or None).  groups: see _conv_bn_relu."""
         fs = ensure_flat(self.m)
         P, Bf = self._tensors()
         B, _, H, W = x.shape
@@ -100,13 +116,16 @@ class UNetEngine:
             raise ValueError(f"UNet input {H}x{W} must be a multiple of 16 in both dimensions")
         dev = x.device
         f = self.f
-        ctx = {"x": x, "B": B, "H": H, "W": W, "training": training, "blocks": {}} if need_grad else None
+        groups = int(groups) if training else 1
+        if groups < 1 or B % groups:
+            raise ValueError(f"batch {B} is not a multiple of bn_groups={groups}")
+        ctx = {"x": x, "B": B, "H": H, "W": W, "training": training, "groups": groups, "blocks": {}} if need_grad else None
 
         def run_block(blk, xin, ldx, cin, h, w, out, ldo):
             saved = [] if need_grad else None
             a1 = torch.empty(B * h * w, blk.cout, device=dev)
-            self._conv_bn_relu(P, Bf, blk, 1, xin, ldx, cin, B, h, w, a1, blk.cout, training, saved)
-            self._conv_bn_relu(P, Bf, blk, 2, a1, blk.cout, blk.cout, B, h, w, out, ldo, training, saved)
+            self._conv_bn_relu(P, Bf, blk, 1, xin, ldx, cin, B, h, w, a1, blk.cout, training, saved, groups)
+            self._conv_bn_relu(P, Bf, blk, 2, a1, blk.cout, blk.cout, B, h, w, out, ldo, training, saved, groups)
             if need_grad:
                 ctx["blocks"][blk.mod] = {"xin": xin, "ldx": ldx, "cin": cin, "h": h, "w": w, "a1": a1, "out": out, "ldo": ldo,
                                           "y1": saved[0][0], "coef1": saved[0][1], "st1": saved[0][2], "y2": saved[1][0],
@@ -144,7 +163,7 @@ class UNetEngine:
         out = torch.empty(B, 1, H, W, device=dev)
         ops.head_fwd(d, f, P["conv.weight"], P["conv.bias"], out, B * H * W, f)
         if training:
-            fs.ibuf.add_(1)                                    # all num_batches_tracked counters at once
+            fs.ibuf.add_(groups)                               # all num_batches_tracked counters at once
         if need_grad:
             ctx.update(cats=cats, ups=ups, d1=d, out=out)
         return out, ctx
@@ -167,6 +186,21 @@ class UNetEngine:
             side = ops.SideStream(dev)
             self._side = side
 
+        NG = ctx.get("groups", 1)
+
+        def bn_bwd(da, ldda, y, coef, st, i, dy, M, cout, blk):
+            """BatchNorm(+ReLU) backward of conv i of a block; per statistics group when the forward ran with bn_groups"""
+            if coef.dim() == 2:
+                ops.bn_bwd(da, ldda, None, 0, y, cout, M, cout, P[blk.key(i, "gamma")], coef[0], coef[1], training, G[blk.key(i, "gamma")],
+                           G[blk.key(i, "beta")], dy, cout, accumulate=True, stat64=st, relu_scale=coef[2], relu_shift=coef[3])
+                return
+            Mg = M // NG
+            for g in range(NG):
+                sl = slice(g * Mg, (g + 1) * Mg)
+                ops.bn_bwd(da[sl], ldda, None, 0, y[sl], cout, Mg, cout, P[blk.key(i, "gamma")], coef[g, 0], coef[g, 1], training,
+                           G[blk.key(i, "gamma")], G[blk.key(i, "beta")], dy[sl], cout, accumulate=True,
+                           stat64=st[g] if st is not None else None, relu_scale=coef[g, 2], relu_shift=coef[g, 3])
+
         def block_bwd(blk, da2, ldda):
             """da2: grad w.r.t. the block output (pixel stride ldda).  Returns grad w.r.t. the block input
             as a fresh [M][cin] tensor, or None for the first encoder block."""
@@ -175,9 +209,7 @@ class UNetEngine:
             M = B * h * w
             dy2 = torch.empty(M, cout, device=dev)
             # ReLU mask recomputed from y with the forward's scale/shift: the activation is not re-read
-            ops.bn_bwd(da2, ldda, None, 0, s["y2"], cout, M, cout, P[blk.key(2, "gamma")], s["coef2"][0], s["coef2"][1],
-                       training, G[blk.key(2, "gamma")], G[blk.key(2, "beta")], dy2, cout, accumulate=True, stat64=s["st2"],
-                       relu_scale=s["coef2"][2], relu_shift=s["coef2"][3])
+            bn_bwd(da2, ldda, s["y2"], s["coef2"], s["st2"], 2, dy2, M, cout, blk)
             w2 = P[blk.key(2, "w")]
             side.run(lambda: ops.conv_wgrad(dy2, s["a1"], G[blk.key(2, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cout, KH=3, KW=3,
                                             pad=(1, 1), ldp=cout, ldq=cout, accumulate=True), dy2)
@@ -186,9 +218,7 @@ class UNetEngine:
             ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout,
                            w_src=("flipT", w2))
             dy1 = torch.empty(M, cout, device=dev)       # (dy2 may still be read by its wgrad on the side stream)
-            ops.bn_bwd(da1, cout, None, 0, s["y1"], cout, M, cout, P[blk.key(1, "gamma")], s["coef1"][0], s["coef1"][1],
-                       training, G[blk.key(1, "gamma")], G[blk.key(1, "beta")], dy1, cout, accumulate=True, stat64=s["st1"],
-                       relu_scale=s["coef1"][2], relu_shift=s["coef1"][3])
+            bn_bwd(da1, cout, s["y1"], s["coef1"], s["st1"], 1, dy1, M, cout, blk)
             if cin == 1:
                 side.run(lambda: ops.conv_c1_wgrad(s["xin"], dy1, cout, G[blk.key(1, "w")], None, B, h, w, cout, accumulate=True), dy1)
                 return None

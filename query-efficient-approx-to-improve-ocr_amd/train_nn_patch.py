@@ -26,7 +26,7 @@ from utils import compare_labels, get_text_stack, handle_optuna_trial, pred_to_s
 class TrainNNPrep(TrainerCore):
     def __init__(self, args, optuna_trial=None, backend=None, train_set=None, val_set=None, ocr=None):
         self.optuna_trial = optuna_trial
-        self.batch_size = 1
+        self.batch_size = max(1, int(getattr(args, "docs_per_step", 1) or 1))   # documents per step (reference: 1, train_nn_patch.py:37)
         self.random_seed = args.random_seed
         self.weight_decay = args.weight_decay
         self.update_CRNN = args.update_CRNN
@@ -46,10 +46,10 @@ class TrainNNPrep(TrainerCore):
         if not self.val_subset_size:
             self.val_subset_size = len(val_set)
         idx = torch.randperm(len(train_set))[: self.train_subset_size]
-        idx = qdist.equal_shards(idx, 1)                        # data parallel: the same number of documents (= steps) on every rank
+        idx = qdist.equal_shards(idx, self.batch_size)          # data parallel: the same number of steps on every rank
         self._train_idx = idx
         self._collate = collate
-        self.loader_train = torch.utils.data.DataLoader(train_set, batch_size=1, drop_last=True, collate_fn=collate,
+        self.loader_train = torch.utils.data.DataLoader(train_set, batch_size=self.batch_size, drop_last=True, collate_fn=collate,
                                                         sampler=torch.utils.data.SubsetRandomSampler(idx))
         self.train_set_size, self.val_set_size = len(idx), len(val_set)
         self.num_subset_images = int(args.image_prop * self.train_set_size) if args.image_prop else None
@@ -82,16 +82,19 @@ class TrainNNPrep(TrainerCore):
                 # a fresh subset of THIS rank's documents per epoch (train_nn_patch.py:209-218); the draw is rank-identical
                 # and every shard has the same length, so the step counts stay equal
                 sub = self._train_idx[torch.randperm(self.train_set_size)[: self.num_subset_images]]
-                self.loader_train = torch.utils.data.DataLoader(self.dataset, batch_size=1, drop_last=True, collate_fn=self._collate,
+                self.loader_train = torch.utils.data.DataLoader(self.dataset, batch_size=self.batch_size, drop_last=True, collate_fn=self._collate,
                                                                 sampler=torch.utils.data.SubsetRandomSampler(sub))
             for images, labels_dicts, names in self.loader_train:
                 # ---------------- Phase A ----------------
                 self._set_phase_a()
                 strip_names = []
-                for i in range(len(labels_dicts)):
-                    X_var = images[i].unsqueeze(0).to(self.device)
+                n_docs = len(labels_dicts)
+                X_all = (images if torch.is_tensor(images) else torch.stack(list(images))).to(self.device)
+                with torch.no_grad():                            # eval-mode BatchNorm: a document's output does not depend on its batch
+                    preds_all = self.prep_model(X_all) if n_docs > 1 else None
+                for i in range(n_docs):
                     with torch.no_grad():
-                        pred = self.prep_model(X_var)[0]
+                        pred = preds_all[i] if preds_all is not None else self.prep_model(X_all[i:i + 1])[0]
                         crops_all, labels = get_text_stack(pred, labels_dicts[i], self.input_size)
                     n_strips = crops_all.shape[0]
                     strip_names = self._strip_names(labels, names[i])
@@ -135,14 +138,37 @@ class TrainNNPrep(TrainerCore):
                     self._step_crnn()
                 # ---------------- Phase B ----------------
                 self._set_phase_b()
-                for i in range(len(labels_dicts)):
-                    X_var = images[i].unsqueeze(0).to(self.device)
-                    img_out = self.prep_model(X_var)[0]
-                    crops, labels = get_text_stack(img_out, labels_dicts[i], self.input_size)
+                if n_docs > 1:
+                    # [new] --docs_per_step N: ONE cleaner pass over the N documents with per-document BatchNorm statistics (the
+                    # values of N sequential passes), ONE CRNN pass over all their strips (BatchNorm in eval mode: batch-independent);
+                    # the N per-document losses of :327-328 are summed and back-propagated once = the accumulated gradients of :329
+                    img_all = self.prep_model(X_all, bn_groups=n_docs)
+                    stacks = [get_text_stack(img_all[i], labels_dicts[i], self.input_size) for i in range(n_docs)]
+                    crops = torch.cat([c for c, _ in stacks])
+                    scores = self.crnn_model(crops)
+                    total, a = None, 0
+                    for i, (c, labels) in enumerate(stacks):
+                        b = a + c.shape[0]
+                        sc = scores[:, a:b, :]
+                        y = torch.tensor([self.char_to_index[ch] for ch in "".join(labels)], dtype=torch.int)
+                        pred_size = torch.tensor([sc.shape[0]] * c.shape[0], dtype=torch.int)
+                        y_size = torch.tensor([len(l) for l in labels], dtype=torch.int)
+                        loss = self._get_loss(sc, y, pred_size, y_size, img_all[i])
+                        total = loss if total is None else total + loss
+                        self._update_cers(sc, labels, self._strip_names(labels, names[i]))
+                        training_loss += loss.item()
+                        if step % 100 == 0:
+                            print("Iteration: %d => %f" % (step, loss.item()))
+                        step += 1
+                        a = b
+                    total.backward()
+                else:
+                    img_out = self.prep_model(X_all)[0]
+                    crops, labels = get_text_stack(img_out, labels_dicts[0], self.input_size)
                     scores, y, pred_size, y_size = self._call_model(crops, labels)
                     loss = self._get_loss(scores, y, pred_size, y_size, img_out)
                     loss.backward()
-                    self._update_cers(scores, labels, self._strip_names(labels, names[i]))
+                    self._update_cers(scores, labels, self._strip_names(labels, names[0]))
                     training_loss += loss.item()
                     if step % 100 == 0:
                         print("Iteration: %d => %f" % (step, loss.item()))

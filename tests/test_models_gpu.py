@@ -278,6 +278,53 @@ def test_unet_other_size_vs_oracle():
     assert y.shape == (2, 1, 48, 160) and (y.cpu().double() - y_r).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 32, 128), (2, 1, 80, 256), (3, 1, 400, 512)])
+def test_unet_bn_groups_equal_sequential_passes(shape):
+    """[new] UNet.forward(x, bn_groups=N) (the patch flow's --docs_per_step): N groups of images through ONE pass with
+    BatchNorm statistics per group == N sequential train-mode passes of the reference (one document per call,
+    train_nn_patch.py:318-321): outputs, the gradients of a sum of per-group losses, running statistics after the N ordered
+    updates, num_batches_tracked.  (3, 1, 400, 512) = three POS-sized documents: levels 4-5 are 50x64 and 25x32 pixels, which run
+    on the generic tile whose statistics blocks straddle images — why the grouped path takes its statistics in a separate pass."""
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    N, per, Hh, Ww = shape
+    su = mo.default_init_state(mo.unet_state_shapes(), 17)
+    x = torch.rand(N * per, 1, Hh, Ww, generator=torch.Generator().manual_seed(18)).cuda()
+    wgt = torch.rand(N * per, 1, Hh, Ww, generator=torch.Generator().manual_seed(19)).cuda()
+
+    def make():
+        net = UNet()
+        net.load_state_dict(su)
+        net = net.cuda().train()
+        net.zero_grad()
+        return net
+    seq = make()
+    outs = []
+    for g in range(N):
+        sl = slice(g * per, (g + 1) * per)
+        o = seq(x[sl])
+        (F.mse_loss(o, torch.ones_like(o)) + (o * wgt[sl]).mean()).backward()
+        outs.append(o.detach())
+    fused = make()
+    o_all = fused(x, bn_groups=N)
+    total = 0
+    for g in range(N):
+        sl = slice(g * per, (g + 1) * per)
+        total = total + F.mse_loss(o_all[sl], torch.ones_like(o_all[sl])) + (o_all[sl] * wgt[sl]).mean()
+    total.backward()
+    torch.cuda.synchronize()
+    # the grouped pass sums its statistics in another order (separate fp64 pass vs the conv epilogue's partials): equal to fp64
+    # rounding, i.e. the fp32 coefficients agree except at rounding boundaries
+    assert (o_all.detach() - torch.cat(outs)).abs().max().item() <= 2e-6
+    for (n, a), (_, b) in zip(fused.named_parameters(), seq.named_parameters()):
+        assert _rel(a.grad, b.grad) < 2e-5, n
+    for (n, a), (_, b) in zip(fused.named_buffers(), seq.named_buffers()):
+        if a.is_floating_point():
+            assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), n
+        else:
+            assert int(a) == int(b) == N, n
+
+
 def test_replica_groups_equal_sequential_passes():
     """R jitter replicas fused into the batch dimension with per-replica-group BatchNorm == R sequential
     CRNN passes of the reference loop: same log-probs, same gradients (sum of the replica losses), same

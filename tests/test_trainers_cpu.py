@@ -112,6 +112,67 @@ def test_patch_trainer_plumbing(tmp_path):
     assert ocr.count_calls > 0
 
 
+def test_patch_trainer_docs_per_step_equals_the_sequential_loop(tmp_path, monkeypatch):
+    """[new] --docs_per_step N (SURVEY §8 f2 "multi-document batching"): Phase B runs the N documents through the cleaner as one
+    batch with per-document BatchNorm statistics and all their strips through the CRNN as one batch, sums the N per-document
+    losses and back-propagates once.  Against the reference's loop written out (train_nn_patch.py:318-329: per document forward,
+    loss, backward — gradients accumulate) on the same models: the gradient Adam(UNet) consumes and the UNet's running statistics."""
+    import torch.nn.functional as F
+    from datasets.synthetic import SyntheticPatches
+    from ocr_helper.stub_helper import StubHelper
+    from oracle.modules import OracleCRNN, OracleUNet
+    from train_nn_patch import TrainNNPrep
+    from utils import get_text_stack
+    tr_set = SyntheticPatches(4, seed=1, strips=(2, 3), pad_shape=(80, 256))
+    args = _args("p", tmp_path / "exp", inner_limit=0, docs_per_step=2)
+    t = TrainNNPrep(args, backend=oracle_backend(), train_set=tr_set, val_set=SyntheticPatches(1, seed=2, strips=(2, 2), pad_shape=(80, 256),
+                                                                                             include_name=False), ocr=StubHelper())
+    assert len(t.loader_train) == 2                                              # 4 documents, 2 per step
+    seen, grads = [], []
+    fwd = type(t.prep_model).forward                                             # patched on the class: the trainer pickles the module
+
+    def spy_fwd(self, x, bn_groups=1):
+        if torch.is_grad_enabled() and self is t.prep_model:
+            seen.append((x.detach().clone(), bn_groups))
+        return fwd(self, x, bn_groups=bn_groups)
+    monkeypatch.setattr(type(t.prep_model), "forward", spy_fwd)
+    step = t._step_prep
+
+    def spy_step(also_crnn=False):
+        if not grads:
+            grads.append(({n: p.grad.detach().clone() for n, p in t.prep_model.named_parameters()},
+                          {n: b.detach().clone() for n, b in t.prep_model.named_buffers()}))
+        step(also_crnn)
+    t._step_prep = spy_step
+    batches = []
+    coll = t._collate
+
+    def spy_collate(items):
+        batches.append(items)
+        return coll(items)
+    t.loader_train = torch.utils.data.DataLoader(tr_set, batch_size=2, shuffle=False, collate_fn=spy_collate)
+    t.train()
+    assert seen[0][1] == 2 and seen[0][0].shape[0] == 2
+    # ---- the reference's loop on identically initialised models
+    prep, crnn = OracleUNet(), OracleCRNN(t.vocab_size)
+    crnn.register_backward_hook(crnn.backward_hook)
+    prep.train(); crnn.train(); crnn.apply(__import__("utils").set_bn_eval)
+    for image, boxes, _name in batches[0]:
+        img_out = prep(image.unsqueeze(0))[0]
+        crops, labels = get_text_stack(img_out, boxes, (32, 128))
+        scores = crnn(crops)
+        y, ysz = H.encode(labels)
+        loss = F.ctc_loss(scores, y, torch.full((len(labels),), scores.shape[0], dtype=torch.int), ysz) + \
+            F.mse_loss(img_out, torch.ones_like(img_out)) * args.scalar
+        loss.backward()
+    g_ref = dict(prep.named_parameters())
+    for n, g in grads[0][0].items():
+        ref = g_ref[n].grad
+        assert (g - ref).norm().item() <= 2e-5 * max(ref.norm().item(), 1e-12), n
+    for n, b in prep.named_buffers():
+        assert torch.allclose(grads[0][1][n].double(), b.double(), rtol=1e-6, atol=1e-7), n
+
+
 # ----------------------------------------------------------------------------- data parallel (gloo, 2 ranks)
 def _dp_worker(rank, world, port, tmp, out):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

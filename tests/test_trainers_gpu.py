@@ -67,6 +67,31 @@ def test_patch_trainer_hip(tmp_path):
     assert set(json.load(open(tmp_path / "exp" / "cers" / "all_cers.json")).keys()) == set(names)
 
 
+def test_patch_trainer_hip_docs_per_step(tmp_path):
+    """[new] --docs_per_step 2 on the HIP path: two documents per optimiser step through one cleaner pass (per-document BatchNorm
+    groups) and one CRNN pass; half the steps, every strip's CER refreshed, finite weights."""
+    from datasets.synthetic import SyntheticPatches
+    from train_nn_patch import TrainNNPrep
+    tr = SyntheticPatches(4, seed=1)
+    names = []
+    for i in range(len(tr)):
+        _, boxes, name = tr[i]
+        names += TrainNNPrep._strip_names([b["label"] for b in boxes], name)
+    cers_path = tmp_path / "cers.json"
+    json.dump({n: (i % 3) / 2 for i, n in enumerate(names)}, open(cers_path, "w"))
+    args = _args("p", tmp_path / "exp", minibatch_subset="topKCER", minibatch_subset_prop=0.5, cers_ocr_path=str(cers_path), inner_limit=2,
+                 docs_per_step=2)
+    t = TrainNNPrep(args, train_set=tr, val_set=SyntheticPatches(1, seed=2, include_name=False))
+    assert len(t.loader_train) == 2
+    steps = []
+    orig = t._step_prep
+    t._step_prep = lambda also_crnn=False: (steps.append(1), orig(also_crnn))[1]
+    t.train()
+    assert len(steps) == 2
+    assert torch.isfinite(torch.cat([p.detach().flatten() for p in t.prep_model.parameters()])).all()
+    assert set(t.sampler.all_cers.keys()) == set(names) and all(len(v) == 1 for v in t.sampler.all_cers.values())
+
+
 @pytest.mark.parametrize("method", ["levenshtein", "self_attention"])
 def test_area_trainer_label_history_weightgens(tmp_path, method):
     """--inner_limit_skip with the non-decaying weight generators: sample-wise CTC (reduction='none') on the HIP path

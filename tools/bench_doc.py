@@ -1,5 +1,6 @@
-"""UNet fwd+bwd on ONE document-sized image [1,1,400,512] (the patch flow's unit, train_nn_patch.py:237-242): ms per pass, the
-conv / wgrad classes' TFLOP/s and the tile each 3x3 layer gets (developer tool, GPU box only)."""
+"""UNet fwd+bwd on N document-sized images [N,1,400,512] (the patch flow's unit is N = 1, train_nn_patch.py:237-242; N > 1 =
+--docs_per_step with per-document BatchNorm groups): ms per pass and per document, the conv / wgrad classes' TFLOP/s and the tile
+each 3x3 layer gets (developer tool, GPU box only).   python tools/bench_doc.py [H W [N]]"""
 import ctypes as C
 import os
 import sys
@@ -15,14 +16,15 @@ from qea import _lib, ops  # noqa: E402
 
 def main():
     H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (400, 512)
+    N = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     torch.manual_seed(0)
     net = UNet().cuda().train()
-    x = torch.rand(1, 1, H, W, device="cuda")
+    x = torch.rand(N, 1, H, W, device="cuda")
     ones = torch.ones_like(x)
 
     def step():
         net.zero_grad()
-        y = net(x)
+        y = net(x, bn_groups=N)
         torch.nn.functional.mse_loss(y, ones).backward()
     for _ in range(3):
         step()
@@ -40,7 +42,7 @@ def main():
     for _ in range(n):
         step()
     torch.cuda.synchronize()
-    out = {"image": [1, 1, H, W], "ms_per_fwd_bwd": round(ms, 3)}
+    out = {"image": [N, 1, H, W], "bn_groups": N, "ms_per_fwd_bwd": round(ms, 3), "ms_per_document": round(ms / N, 3)}
     for name, k in (("conv_igemm", ops.PROF_CONV_IGEMM), ("conv_wgrad", ops.PROF_CONV_WGRAD)):
         q = ops.prof_read(k)
         out[name] = {"tflops": round(q["flops"] / (q["ms"] * 1e-3) / 1e12, 1), "ms_per_pass": round(q["ms"] / n, 3), "launches_per_pass": q["launches"] / n,
