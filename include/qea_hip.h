@@ -62,7 +62,15 @@ int qea_prof_read_split_bf16(int klass, double* flops);
 /* Which matrix instruction the GEMM-class launches use: 0 = split-bf16 tiles where the dispatcher prefers them
  * (default), 1 = every product on v_mfma_f32_32x32x2_f32.  The initial value comes from QEA_MFMA=f32 in the
  * environment; tests and bench.py's native-fp32 leg switch it at run time.  Returns the previous mode, or
- * QEA_ERR_INVALID for a mode other than 0/1 (mode -1 only queries). */
+ * QEA_ERR_INVALID for a mode other than 0/1 (mode -1 only queries).
+ *
+ * PROCESS-GLOBAL STATE, one of two exceptions to "no global mutable state" (the other: the profiling registry above, which
+ * only records).  The mode is read by every GEMM-class entry point at LAUNCH time and selects the kernel, i.e. the summation
+ * order of the results: a caller that flips it while another host thread of the same process is launching changes that
+ * thread's results (both forms are fp32-class — see DESIGN.md §4 — but not bit-identical).  The library is used with one host
+ * thread per GPU process; a process that needs both forms concurrently must serialise the switch with its
+ * launches itself.  A single launch can be pinned regardless of the mode through its descriptor's `tile` field (tiles 1-9: fp32
+ * instruction, 20-25: split-bf16). */
 #define QEA_MFMA_SPLIT_BF16 0
 #define QEA_MFMA_F32 1
 int qea_set_mfma_mode(int mode);
@@ -113,8 +121,10 @@ typedef struct qea_conv_desc {
    * qea_conv_igemm_stats_blocks(d) gives the block count (0: this launch has no such epilogue — run qea_bn_train_stats).
    * qea_bn_train_stats_from_partials turns the partials into the BatchNorm coefficients. */
   double* stats;
-  /* ABI v4: filter of a narrow 3x3 layer (Cin, N in {32, 64}) as bf16 planes in MFMA-fragment order (qea_pack_frag_planes):
-   * operand of the split-bf16 LDS-halo kernel (tile 24); without it such a launch runs on the fp32 halo / generic tiles. */
+  /* ABI v4: filter of a 3x3 pad-1 stride-1 layer as bf16 planes in MFMA-fragment order (qea_pack_frag_planes): operand of the
+   * split-bf16 LDS-halo kernel (tile 24: Cin = 32 or 64k <= 512, N in {32, 64, 128k}; W % 32 == 0 and H % 4 == 0 (8 for Cin = 32),
+   * or — round 3, no ABI change — whole small images per tile: 4x16 / 2x8 pixel images with Cin = 64k, N = 128k);
+   * qea_conv_igemm_wants_frag_planes(d) tells.  Without it such a launch runs on the fp32 halo / generic tiles. */
   const void* w_frag_planes;
 } qea_conv_desc;
 
