@@ -126,6 +126,13 @@ typedef struct qea_conv_desc {
    * or — round 3, no ABI change — whole small images per tile: 4x16 / 2x8 pixel images with Cin = 64k, N = 128k);
    * qea_conv_igemm_wants_frag_planes(d) tells.  Without it such a launch runs on the fp32 halo / generic tiles. */
   const void* w_frag_planes;
+  /* ABI v6: TWO-WAY fp16 split of the LDS-halo kernel (tile 24).  When non-NULL: device pointer to ONE float = the largest finite
+   * |x| of the input tensor (qea_absmax), and w_frag_planes must then hold the FP16 planes of qea_pack_frag_planes_f16.  Both
+   * operands are scaled by powers of two into fp16's range and split into h + l (11 + 11 bits); a product is three
+   * v_mfma_f32_32x32x16_f16 (lh, hl, hh) instead of six bf16 ones, the accumulators are un-scaled in the epilogue (exact).
+   * Same accuracy class as the three-way bf16 split, half the matrix instructions, two thirds of the LDS.
+   * NULL: the bf16 form. */
+  const float* x_absmax;
 } qea_conv_desc;
 
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
@@ -133,6 +140,14 @@ int qea_conv_igemm(const qea_conv_desc* d, void* stream);
 int qea_conv_igemm_uses_split_bf16(const qea_conv_desc* d);
 int qea_conv_igemm_stats_blocks(const qea_conv_desc* d);
 int qea_conv_igemm_wants_frag_planes(const qea_conv_desc* d);
+/* ABI v6.  out[0] = max |x[r*ld + c]| over r < M, c < C with NaN / inf elements ignored (a non-finite element must not decide the
+ * scale of the finite ones: it stays non-finite in the products it enters).  One pass over the tensor; `out` is overwritten. */
+int qea_absmax(const float* x, int32_t ld, int64_t M, int32_t C, float* out, void* stream);
+/* ABI v6.  The filter [N][9][Cin] as two fp16 planes in the fragment order of qea_pack_frag_planes, scaled by the power of two that
+ * qea_f16_scale derives from wmax[0] (= qea_absmax of the filter), followed by one float holding the inverse scale.
+ * qea_pack_frag_planes_f16_bytes gives the buffer size. */
+size_t qea_pack_frag_planes_f16_bytes(int32_t N, int32_t Cin);
+int qea_pack_frag_planes_f16(const float* w, int32_t N, int32_t Cin, const float* wmax, void* planes, void* stream);
 size_t qea_pack_frag_planes_bytes(int32_t N, int32_t Cin);
 int qea_pack_frag_planes(const float* w, int32_t N, int32_t Cin, void* planes, void* stream);
 

@@ -9,6 +9,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // x = h + m + l with three bf16 values, |x - (h+m+l)| <= 2^-24 |x| (each residual is exact in fp32).  A product of two
 // such triples keeps hh, hm, mh, hl, lh, mm (six bf16 MFMAs, fp32 accumulate); the dropped ml, lm, ll are < 2^-23 |ab|.
@@ -24,6 +26,33 @@ __device__ __forceinline__ void qea_split3(const f32x4 v, bf16x4& h, bf16x4& m, 
     m[k] = mk;
     l[k] = (__bf16)r2;
   }
+}
+#endif
+
+// TWO-way fp16 split of a SCALED operand (round 3): xs = x * s with s a power of two chosen from the tensor's largest finite
+// magnitude m so that m * s is in [2^14, 2^15) (qea_f16_scale); h = f16(xs) and l = f16(xs - h) carry 11 + 11 significant bits
+// (+ the sign of l): |xs - (h + l)| <= 2^-24 |xs| — as good as the three bf16 pieces — for every element within 2^-29 of m,
+// and an ABSOLUTE error below 2^-40 m for the smaller ones (fp16 subnormal spacing 2^-24 in scaled units).  A product keeps hh,
+// hl, lh (three v_mfma_f32_32x32x16_f16, fp32 accumulate); the dropped ll is < 2^-22 |ab|.  Non-finite elements do not enter m
+// and stay non-finite in h (inf) / l (NaN).
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void qea_split2_f16(const f32x4 v, float s, f16x4& h, f16x4& l) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float xs = v[k] * s;
+    const _Float16 hk = (_Float16)xs;
+    h[k] = hk;
+    l[k] = (_Float16)(xs - (float)hk);
+  }
+}
+// s = 2^(15 - e) for m = f * 2^e, f in [0.5, 1): bits of the scale and of its inverse from the exponent field of m (m >= 0, finite)
+__device__ __forceinline__ void qea_f16_scale(float m, float& s, float& inv) {
+  const unsigned E = (__float_as_uint(m) >> 23) & 0xffu;     // biased exponent; m = 1.x * 2^(E - 127), floor(log2 m) = E - 127
+  int se = 14 - ((int)E - 127);                                // s = 2^se puts m * s into [2^14, 2^15)
+  if (m == 0.f || E == 0) se = 0;                              // all-zero (or subnormal-only) tensor: nothing to scale
+  se = se > 126 ? 126 : (se < -126 ? -126 : se);
+  s = __uint_as_float((unsigned)(se + 127) << 23);
+  inv = __uint_as_float((unsigned)(127 - se) << 23);
 }
 #endif
 

@@ -11,6 +11,7 @@
 //
 // Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); 2*M*N*K algorithmic flops/launch.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,6 +33,8 @@ struct ConvArgs {
   unsigned xp_zero, wp_zero;
   // fused BatchNorm batch statistics (STATS kernels): per (M-tile, wave row) partial column sums [blocks][N][2] in fp64
   double* stats;
+  // two-way fp16 split (QEA_MFMA_SPLIT_F16): largest finite |x| of the input tensor (device scalar) — the filter's is in its planes
+  const float* xmax;
 };
 
 // Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,
@@ -1008,11 +1011,17 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
 // by side and TH / IMH on top of each other, every image with its own zero columns left and right; rows above / below an image
 // are all zero, so ONE shared zero row (stored row TH) stands for them (the row a tap reads is a compile-time function of (row,
 // kh)).  These levels used to run in the generic implicit-GEMM tile, which gathers and splits every input element once per tap.
-template <int CIN, int COUT, int TH, bool STATS, int IMW = 0>
+// NPL = 3: three bf16 planes, six MFMAs per product.  NPL = 2 (round 3, QEA_MFMA_SPLIT_F16): two fp16 planes of the SCALED
+// operands (qea_split2_f16; scales from the input's abs-max `xmax` and from the tail of the filter planes), three MFMAs per
+// product, two thirds of the LDS; the accumulators are un-scaled in the epilogue (exact: powers of two).
+template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
-                                                               int Ntot, const float* __restrict__ mask, int ldmask, int total) {
+                                                               int Ntot, const float* __restrict__ mask, int ldmask, int total,
+                                                               const float* __restrict__ xmax) {
+  constexpr bool F16 = NPL == 2;
+  typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
   constexpr bool SMALL = IMW != 0;
   constexpr int IMH = SMALL ? IMW / 4 : 1;               // image height in small-image mode
   constexpr int IPX = SMALL ? 32 / IMW : 1, IPY = SMALL ? TH / IMH : 1;   // images per tile, across and down
@@ -1025,7 +1034,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int PLANE = HP * CIN;                       // bf16 elements per plane
   static_assert(MI >= 1 && TH % WM == 0, "tile rows must split over the waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem);         // [3][HP][CIN]
+  __bf16* As = reinterpret_cast<__bf16*>(smem);         // [NPL][HP][CIN] (16-bit elements: bf16, or fp16 when NPL == 2)
+  float sx = 1.f, inv_x = 1.f, inv_w = 1.f;
+  if constexpr (F16) {
+    qea_f16_scale(xmax[0], sx, inv_x);
+    // the filter's inverse scale sits behind its planes (qea_pack_frag_planes_f16)
+    inv_w = reinterpret_cast<const float*>(wf + (size_t)Ntot * 9 * chunks * CIN * NPL)[0];
+  }
 
   const int tiles_x = W / TW, tiles_y = H / TH;
   // Work item = (pixel tile, 128-channel group), `total` of them.  The groups of one tile read the same input halo and get
@@ -1101,12 +1116,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       if (q < HP) {
-        bf16x4 h, m, l;
-        qea_split3(hv[i], h, m, l);
         const int o = q * CIN + swz(q, c4 >> 1) * 8 + (c4 & 1) * 4;
-        *reinterpret_cast<bf16x4*>(As + o) = h;
-        *reinterpret_cast<bf16x4*>(As + PLANE + o) = m;
-        *reinterpret_cast<bf16x4*>(As + 2 * PLANE + o) = l;
+        if constexpr (F16) {
+          f16x4 h, l;
+          qea_split2_f16(hv[i], sx, h, l);
+          *reinterpret_cast<f16x4*>(As + o) = h;
+          *reinterpret_cast<f16x4*>(As + PLANE + o) = l;
+        } else {
+          bf16x4 h, m, l;
+          qea_split3(hv[i], h, m, l);
+          *reinterpret_cast<bf16x4*>(As + o) = h;
+          *reinterpret_cast<bf16x4*>(As + PLANE + o) = m;
+          *reinterpret_cast<bf16x4*>(As + 2 * PLANE + o) = l;
+        }
       }
       q += QS;
     }
@@ -1114,11 +1136,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // filter fragments: wf[n-block][chunk][step = tap*KS + cs][plane][nj][lane][8]; this wave's nj = wn
   constexpr int STEPS = 9 * KS;
-  bf16x8 bq[2][3];
+  frag_t bq[2][NPL];
   auto load_b = [&](int nb, int gst, int buf, int tid) {   // gst = chunk * STEPS + step
-    const bf16x8* wl = reinterpret_cast<const bf16x8*>(wf) + ((tid >> 6) % WN) * 64 + (tid & 63) + (size_t)nb * chunks * STEPS * 3 * WN * 64;
+    const frag_t* wl = reinterpret_cast<const frag_t*>(wf) + ((tid >> 6) % WN) * 64 + (tid & 63) + (size_t)nb * chunks * STEPS * NPL * WN * 64;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bq[buf][pl] = wl[(size_t)(gst * 3 + pl) * WN * 64];
+    for (int pl = 0; pl < NPL; ++pl) bq[buf][pl] = wl[(size_t)(gst * NPL + pl) * WN * 64];
   };
 
   int vb = blockIdx.x;
@@ -1155,7 +1177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // A fragments of (step, row) — flat index f = st * MI + i — are read ONE fragment row ahead of their MFMAs, across step
       // boundaries too: the three ds_read_b128 of row f + 1 are issued before the six MFMAs of row f (hipcc otherwise reads just
       // in time and every row starts with an exposed LDS round trip: 239-250 -> 261-269 TFLOP/s on the 512-channel layers)
-      auto read_a = [&](int st, int i, bf16x8* a) {
+      auto read_a = [&](int st, int i, frag_t* a) {
         const int tap = st / KS, cs = st % KS;
         const int kh = tap / 3, kw = tap % 3;
         int hp;
@@ -1167,14 +1189,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           hp = (wm * MI + i + kh) * HW_ + fr + kw;
         }
         const __bf16* src = As + hp * CIN + swz(hp, cs * 2 + fh) * 8;
-        a[0] = *reinterpret_cast<const bf16x8*>(src);
-        a[1] = *reinterpret_cast<const bf16x8*>(src + PLANE);
-        a[2] = *reinterpret_cast<const bf16x8*>(src + 2 * PLANE);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) a[pl] = *reinterpret_cast<const frag_t*>(src + pl * PLANE);
       };
-      bf16x8 ar[2][3];
-#ifdef QEA_HALO_TMPACC
-      f32x16 tq[2];
-#endif
+      frag_t ar[2][NPL];
       read_a(0, 0, ar[0]);
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
@@ -1185,52 +1203,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const int f = st * MI + i;
-          const bf16x8* a = ar[f & 1];
+          const frag_t* a = ar[f & 1];
           const bool more = f + 1 < STEPS * MI;
           if (more) read_a((f + 1) / MI, (f + 1) % MI, ar[(f + 1) & 1]);
-          // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
-#ifdef QEA_HALO_TMPACC
-          // the 16 products of this k-step are summed from ZERO (roundings at the magnitude of one k-step's partial sum) and join
-          // the running sum by ONE round-to-nearest VALU add: the MFMA adder truncates addends it shifts under a dominant C
-          // (tools/micro/mfma_bias.hip: mean -0.003 ulp, rms 0.41 ulp per op) — six such accumulations per k-step into the long
-          // chain were both the random and the pixel-correlated part of the split kernels' error.  The add of row f - 1 is issued
-          // behind the MFMAs of row f (two partial tiles alive), so it never waits for the matrix pipe.
-          const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          f32x16& t = tq[f & 1];
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[cb][0], z16, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][2], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][1], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][0], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][1], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][0], t, 0, 0, 0);
-          // (the empty asm pins each sum at its place in program order: instruction selection otherwise sinks all 144 adds of a
-          // chunk below its last MFMA and spills every partial tile)
-          if (f > 0) {
-            acc[(f - 1) % MI] += tq[(f - 1) & 1];
-            asm volatile("" : "+v"(acc[(f - 1) % MI]));
+          if constexpr (F16) {
+            // smallest terms first (ll is dropped): lh, hl, hh
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bq[cb][0], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[cb][1], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[cb][0], acc[i], 0, 0, 0);
+            if (more) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two LDS reads of row f + 1 ...
+              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... ahead of the three MFMAs of row f
+            }
           }
-          if (!more) {
-            acc[i] += t;
-            asm volatile("" : "+v"(acc[i]));
-          }
-          if (more) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the three LDS reads of row f + 1 ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... ahead of the six MFMAs of row f ...
-            __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // ... and the adds of row f - 1 behind them
-          }
-          __builtin_amdgcn_sched_barrier(0);                     // nothing sinks below its row (the adds would pile up as spills)
-          continue;
-#else
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[cb][0], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][2], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][1], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][0], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][1], acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][0], acc[i], 0, 0, 0);
-#endif
-          if (more) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the three LDS reads of row f + 1 ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... ahead of the six MFMAs of row f
+          else {
+            // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[cb][0], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][2], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][1], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[cb][0], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][1], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[cb][0], acc[i], 0, 0, 0);
+            if (more) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the three LDS reads of row f + 1 ...
+              __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... ahead of the six MFMAs of row f
+            }
           }
         }
       }
@@ -1260,6 +1257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           prow = (size_t)(cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0 + px;
         }
         float v = acc[i][r];
+        if constexpr (F16) v = (v * inv_x) * inv_w;       // un-scale: exact (powers of two), one factor at a time (their product may leave the fp32 range)
         if (scale && bias) v = __fmaf_rn(v, esc, ebi);
         else if (scale) v *= esc;
         else if (bias) v += ebi;
@@ -1319,10 +1317,43 @@ __global__ void pack_frag_planes_kernel(const float* __restrict__ w, __bf16* __r
   for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + ((((size_t)gst * 3 + p) * WNr + nj) * 64 + lane) * 8) = pl[p];
 }
 
-template <int CIN, int COUT, int TH, bool STATS, int IMW = 0>
+// the fp16 two-plane form of pack_frag_planes_kernel: [n-block][chunk][step][plane h, l][nj][lane][8 fp16] of the filter SCALED by
+// s_w (qea_f16_scale of the filter's abs-max `wmax`), followed — at element offset N * 9 * Cin * 2 — by one float: 1 / s_w
+__global__ void pack_frag_planes_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int N, int Cin, int CW,
+                                            const float* __restrict__ wmax) {
+  const int NB = N > 128 ? 128 : N;
+  const int KSr = CW / 16, WNr = NB / 32, chunks = Cin / CW;
+  float sw, inv;
+  qea_f16_scale(wmax[0], sw, inv);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;         // (n-block, chunk, step, nj, lane)
+  if (i == 0) reinterpret_cast<float*>(dst + (size_t)N * 9 * Cin * 2)[0] = inv;
+  if (i >= (N / NB) * chunks * 9 * KSr * WNr * 64) return;
+  const int lane = i & 63;
+  const int nj = (i >> 6) % WNr;
+  const int gst = (i >> 6) / WNr;
+  const int nbk = gst / (chunks * 9 * KSr);
+  const int chunk = (gst / (9 * KSr)) % chunks, st = gst % (9 * KSr);
+  const int tap = st / KSr, cs = st % KSr;
+  const int n = nbk * NB + nj * 32 + (lane & 31);
+  const float* src = w + ((size_t)n * 9 + tap) * Cin + chunk * CW + cs * 16 + 8 * (lane >> 5);
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+  f16x4 h0, l0, h1, l1;
+  qea_split2_f16(v0, sw, h0, l0);
+  qea_split2_f16(v1, sw, h1, l1);
+  f16x8 pl[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pl[0][k] = h0[k]; pl[0][k + 4] = h1[k];
+    pl[1][k] = l0[k]; pl[1][k + 4] = l1[k];
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) *reinterpret_cast<f16x8*>(dst + ((((size_t)gst * 2 + p) * WNr + nj) * 64 + lane) * 8) = pl[p];
+}
+
+template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3>
 int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
-  constexpr size_t lds = IMW ? (size_t)3 * (TH + 1) * (32 / IMW) * (IMW + 2) * CIN * 2 : (size_t)3 * (TH + 2) * 34 * CIN * 2;
-  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS, IMW>;
+  constexpr size_t lds = IMW ? (size_t)NPL * (TH + 1) * (32 / IMW) * (IMW + 2) * CIN * 2 : (size_t)NPL * (TH + 2) * 34 * CIN * 2;
+  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS, IMW, NPL>;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr_rc != (int)hipSuccess) {
     qea_set_error("qea_conv_igemm(halo bf3): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
@@ -1345,12 +1376,14 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
   // then both in their MFMA phase — and lose the overlap that staggered dispatch gives: 150-159 vs 159-166 TFLOP/s measured)
   const unsigned grid = (total > resident && COUT > 32) ? (unsigned)resident : (unsigned)total;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
-                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total);
+                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total, a.xmax);
   return QEA_OK;
 }
 
 template <int CIN, int COUT, int TH, int IMW = 0>
 int launch_halo_bf3(const ConvArgs& a, hipStream_t s) {
+  if (a.xmax)                                              // two-way fp16 split: the caller gave the input's abs-max and fp16 filter planes
+    return a.stats ? launch_halo_bf3_<CIN, COUT, TH, true, IMW, 2>(a, s) : launch_halo_bf3_<CIN, COUT, TH, false, IMW, 2>(a, s);
   return a.stats ? launch_halo_bf3_<CIN, COUT, TH, true, IMW>(a, s) : launch_halo_bf3_<CIN, COUT, TH, false, IMW>(a, s);
 }
 
@@ -1520,6 +1553,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW; a.N = d->N;
   a.KH = d->KH; a.KW = d->KW; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
   a.ldx = d->ldx; a.ldy = d->ldy; a.ldmask = d->ldmask; a.relu = d->relu; a.accumulate = d->accumulate; a.out_mode = d->out_mode;
+  a.xmax = nullptr;
   a.M = d->B * d->OH * d->OW;
   a.K = d->KH * d->KW * d->Cin;
   a.m_tiles = a.n_tiles = 0;
@@ -1559,6 +1593,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     case 4: rc = launch_halo_any(d, a, s); break;
     case 24:                                               // split-bf16 LDS-halo kernel of the narrow layers: filter in fragment-order planes
       a.wp = (const char*)d->w_frag_planes;
+      a.xmax = d->x_absmax;                                // non-NULL: fp16 planes + scales (ABI v6)
       rc = launch_halo_bf3_any(d, a, s);
       break;
     case 1: rc = launch<128, 128, 2, 2, 32>(a, s); break;
@@ -1625,6 +1660,18 @@ extern "C" int qea_pack_frag_planes(const float* w, int32_t N, int32_t Cin, void
   const int total = 9 * (Cin / 16) * (N / 32) * 64;
   hipLaunchKernelGGL(pack_frag_planes_kernel, dim3(qea_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)planes, N, Cin,
                      Cin == 32 ? 32 : 64);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" size_t qea_pack_frag_planes_f16_bytes(int32_t N, int32_t Cin) { return (size_t)N * 9 * Cin * 4 + 16; }
+
+extern "C" int qea_pack_frag_planes_f16(const float* w, int32_t N, int32_t Cin, const float* wmax, void* planes, void* stream) {
+  QEA_REQUIRE(w && planes && wmax && (N == 32 || N == 64 || (N > 0 && N % 128 == 0)) && (Cin == 32 || (Cin % 64 == 0 && Cin <= 512)),
+              "qea_pack_frag_planes_f16: N in {32, 64, 128k}, Cin = 32 or a multiple of 64 up to 512");
+  const int total = 9 * (Cin / 16) * (N / 32) * 64;
+  hipLaunchKernelGGL(pack_frag_planes_f16_kernel, dim3(qea_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)planes, N, Cin,
+                     Cin == 32 ? 32 : 64, wmax);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

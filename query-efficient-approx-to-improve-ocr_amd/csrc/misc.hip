@@ -351,3 +351,40 @@ extern "C" int qea_edit_distance(const int32_t* pred_tokens, int32_t ldp, const 
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// largest finite magnitude of a strided [M][C] tensor (the scale source of the two-way fp16 split, ABI v6).  Non-negative floats
+// order like their bit patterns, so the block results meet in one atomicMax on the bits; NaN / inf are skipped.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int ld, long long M, int C, unsigned* __restrict__ out) {
+  const int cols = C / 4;
+  const long long n = M * cols;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols;
+    const int ct = (int)(i - r * cols);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + ct * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = fabsf(v[k]);
+      m = (a <= 3.4028234663852886e38f && a > m) ? a : m;      // the comparison is false for NaN; inf is excluded by the bound
+    }
+  }
+  m = qea_wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+extern "C" int qea_absmax(const float* x, int32_t ld, int64_t M, int32_t C, float* out, void* stream) {
+  QEA_REQUIRE(x && out && M > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "qea_absmax: bad arguments (C and ld multiples of 4)");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) {
+    qea_set_error("qea_absmax: memset failed");
+    return QEA_ERR_LAUNCH;
+  }
+  const long long n = (long long)M * (C / 4);
+  const int grid = (int)(n / 256 / 8 > 2048 ? 2048 : (n / 256 / 8 < 1 ? 1 : n / 256 / 8));
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, x, ld, (long long)M, C, (unsigned*)out);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}

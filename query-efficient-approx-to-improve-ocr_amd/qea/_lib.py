@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
         ("stride_h", _i32), ("stride_w", _i32),
         ("ldx", _i32), ("ldy", _i32), ("ldmask", _i32),
         ("relu", _i32), ("accumulate", _i32), ("out_mode", _i32), ("tile", _i32),
-        ("x_planes", _fp), ("w_planes", _fp), ("stats", _fp), ("w_frag_planes", _fp),
+        ("x_planes", _fp), ("w_planes", _fp), ("stats", _fp), ("w_frag_planes", _fp), ("x_absmax", _fp),
     ]
 
 

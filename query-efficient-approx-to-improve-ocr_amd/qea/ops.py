@@ -4,6 +4,7 @@ Every function takes CUDA (ROCm) fp32 tensors, passes raw device pointers + the 
 stream to libqea_hip.so and raises on any error.  No CPU implementation exists here.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -119,15 +120,25 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
                       stride_h=stride[0], stride_w=stride[1], ldx=ldx, ldy=ldy, ldmask=ldmask,
                       relu=int(relu), accumulate=int(accumulate), out_mode=out_mode, tile=tile, x_planes=None, w_planes=None, stats=None,
                       w_frag_planes=None)
-    frag = None
+    frag = xmax = None
     if PRESPLIT["on"] and L.qea_conv_igemm_wants_frag_planes(C.byref(d)):
-        # narrow 3x3 layer on the split-bf16 LDS-halo kernel: its filter in fragment-order planes (a few hundred KB, cached)
+        # 3x3 layer on the split LDS-halo kernel: its filter in fragment-order planes (a few hundred KB, cached)
+        f16 = SPLIT_F16["on"]
+
         def build():
+            if f16:
+                out = torch.empty(L.qea_pack_frag_planes_f16_bytes(N, Cin), dtype=torch.uint8, device=x.device)
+                wmax = absmax(w, 9 * Cin, N, 9 * Cin)
+                _lib.check(L.qea_pack_frag_planes_f16(_ptr(w), N, Cin, _ptr(wmax), out.data_ptr(), _stream()), "qea_pack_frag_planes_f16")
+                return out
             out = torch.empty(L.qea_pack_frag_planes_bytes(N, Cin), dtype=torch.uint8, device=x.device)
             _lib.check(L.qea_pack_frag_planes(_ptr(w), N, Cin, out.data_ptr(), _stream()), "qea_pack_frag_planes")
             return out
-        frag = weight_cached(("frag", w_src[0], N, Cin), w_src[1], build) if w_src is not None else build()
+        frag = weight_cached(("fragf16" if f16 else "frag", w_src[0], N, Cin), w_src[1], build) if w_src is not None else build()
         d.w_frag_planes = frag.data_ptr()
+        if f16:
+            xmax = absmax(x, ldx, B * H * W, Cin)         # (v1: a pass of its own over the input; producers' epilogues can carry it)
+            d.x_absmax = xmax.data_ptr()
     elif PRESPLIT["on"] and Cin % 16 == 0 and L.qea_conv_igemm_uses_split_bf16(C.byref(d)):
         K = KH * KW * Cin
         if N * K * 6 < (1 << 31) - 256:
@@ -167,17 +178,34 @@ def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride
     _lib.check(L.qea_conv_wgrad(C.byref(d), _stream()), "qea_conv_wgrad")
 
 
+# "split_f16" (default since round 3): the LDS-halo 3x3 kernels take the TWO-way fp16 split (ABI v6: three MFMAs per product,
+# operands scaled by powers of two from their abs-max); every other GEMM-class launch as in "split_bf16".  QEA_SPLIT=bf16 in the
+# environment keeps the three-way bf16 split everywhere.
+SPLIT_F16 = {"on": os.environ.get("QEA_SPLIT", "f16").lower() != "bf16"}
+
+
 def set_mfma_mode(mode):
-    """"split_bf16" (default dispatch) or "f32" (every product on the fp32 MFMA); returns the previous mode's name."""
-    names = ("split_bf16", "f32")
-    prev = _lib.lib().qea_set_mfma_mode(names.index(mode))
+    """"split_bf16" (default dispatch), "split_f16" (as split_bf16 with the two-way fp16 split in the LDS-halo convs) or "f32"
+    (every product on the fp32 MFMA); returns the previous mode's name."""
+    lib_mode = {"split_bf16": 0, "split_f16": 0, "f32": 1}[mode]
+    prev_name = mfma_mode()
+    prev = _lib.lib().qea_set_mfma_mode(lib_mode)
     if prev < 0:
         _lib.check(prev, "qea_set_mfma_mode")
-    return names[prev]
+    SPLIT_F16["on"] = mode == "split_f16"
+    return prev_name
 
 
 def mfma_mode():
-    return ("split_bf16", "f32")[_lib.lib().qea_set_mfma_mode(-1)]
+    m = ("split_bf16", "f32")[_lib.lib().qea_set_mfma_mode(-1)]
+    return "split_f16" if (m == "split_bf16" and SPLIT_F16["on"]) else m
+
+
+def absmax(x, ld, M, Cc):
+    """device scalar: the largest finite |x| of a strided [M][Cc] tensor (one pass; the scale source of the fp16 split)"""
+    out = torch.empty(1, device=x.device)
+    _lib.check(_lib.lib().qea_absmax(_ptr(x), ld, M, Cc, _ptr(out), _stream()), "qea_absmax")
+    return out
 
 
 _overlap = {"on": None}

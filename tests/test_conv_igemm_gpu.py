@@ -188,7 +188,7 @@ def test_non_finite_operand_stays_confined_and_visible():
     xb[1, 4, 10, 7] = float("inf")
     hit = torch.zeros(B, H, W, dtype=torch.bool)
     hit[1, 3:6, 9:12] = True
-    for mode in ("split_bf16", "f32"):
+    for mode in ("split_f16", "split_bf16", "f32"):
         prev = ops.set_mfma_mode(mode)
         try:
             ys = []

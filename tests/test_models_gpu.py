@@ -315,13 +315,18 @@ def test_unet_bn_groups_equal_sequential_passes(shape):
             assert int(a) == int(b) == N, n
 
 
-def test_replica_groups_equal_sequential_passes():
+@pytest.mark.parametrize("mode", ["split_f16", "split_bf16"])
+def test_replica_groups_equal_sequential_passes(mode):
     """R jitter replicas fused into the batch dimension with per-replica-group BatchNorm == R sequential
     CRNN passes of the reference loop: same log-probs, same gradients (sum of the replica losses), same
-    running statistics."""
+    running statistics.  Bit for bit in the three-way bf16 split (every output element has the same summation
+    order in both forms); in the two-way fp16 split the operands' power-of-two scale comes from the abs-max of the WHOLE
+    tensor a launch consumes — R*k strips there, k strips here — so the forms agree to fp32 rounding instead."""
     from models.model_crnn import CRNN
     from oracle import model_oracle as mo
+    from qea import ops
     from qea.loss import CTCLoss
+    prev_mode = ops.set_mfma_mode(mode)
     R, k = 3, 4
     sc = mo.seeded_state(mo.crnn_state_shapes(), 7)
     x = torch.stack([H.synth_images(k, 50 + r) for r in range(R)]).reshape(R * k, 1, 32, 128).cuda()
@@ -349,11 +354,20 @@ def test_replica_groups_equal_sequential_passes():
         y, ysz = H.encode(labels[r])
         total = total + CTCLoss()(lp_all[:, r * k:(r + 1) * k, :], y, ins, ysz)
     total.backward()
-    assert torch.equal(lp_all.detach(), torch.cat(lps, dim=1))
+    ops.set_mfma_mode(prev_mode)
+    if mode == "split_bf16":
+        assert torch.equal(lp_all.detach(), torch.cat(lps, dim=1))
+    else:
+        assert (lp_all.detach() - torch.cat(lps, dim=1)).abs().max().item() < 5e-6
     for (n, a), (_, b) in zip(fused.named_parameters(), seq.named_parameters()):
+        if mode != "split_bf16" and n in ("convo.conv5.bias", "convo.conv6.bias"):
+            continue                                    # exactly zero in exact arithmetic (a bias in front of a batch-statistics BN): rounding noise
         assert _rel(a.grad, b.grad) < 2e-5, n
     for (n, a), (_, b) in zip(fused.named_buffers(), seq.named_buffers()):
-        assert torch.equal(a, b), n
+        if mode == "split_bf16" or not a.is_floating_point():
+            assert torch.equal(a, b), n
+        else:
+            assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), n
 
 
 @pytest.mark.parametrize("g", [2, 0])

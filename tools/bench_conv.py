@@ -37,9 +37,17 @@ def main():
         wp = torch.empty(L.qea_split_planes_bytes(Cout, 9 * Cin), dtype=torch.uint8, device="cuda")
         _lib.check(L.qea_split_planes(x.data_ptr(), Cin, B * H * W, Cin, xp.data_ptr(), s))
         _lib.check(L.qea_split_planes(w.data_ptr(), 9 * Cin, Cout, 9 * Cin, wp.data_ptr(), s))
-        narrow = (Cin == 32 or (Cin % 64 == 0 and Cin <= 512)) and (Cout in (32, 64) or Cout % 128 == 0)
-        fp = None
-        if narrow:
+        narrow = (Cin == 32 or (Cin % 64 == 0 and Cin <= 512)) and (Cout in (32, 64) or Cout % 128 == 0) and (
+            W % 32 == 0 or ((H, W) in ((4, 16), (2, 8)) and Cin % 64 == 0 and Cout % 128 == 0))
+        fp = xmax = None
+        f16 = os.environ.get("QEA_SPLIT", "") == "f16"           # two-way fp16 split of the halo kernel (ABI v6)
+        if narrow and f16:
+            from qea import ops
+            fp = torch.empty(L.qea_pack_frag_planes_f16_bytes(Cout, Cin), dtype=torch.uint8, device="cuda")
+            wmax = ops.absmax(w, 9 * Cin, Cout, 9 * Cin)
+            _lib.check(L.qea_pack_frag_planes_f16(w.data_ptr(), Cout, Cin, wmax.data_ptr(), fp.data_ptr(), s))
+            xmax = ops.absmax(x, Cin, B * H * W, Cin)
+        elif narrow:
             fp = torch.empty(L.qea_pack_frag_planes_bytes(Cout, Cin), dtype=torch.uint8, device="cuda")
             _lib.check(L.qea_pack_frag_planes(w.data_ptr(), Cout, Cin, fp.data_ptr(), s))
         for tile in tiles:
@@ -49,7 +57,8 @@ def main():
                               B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad_h=1, pad_w=1,
                               stride_h=1, stride_w=1, ldx=Cin, ldy=Cout, ldmask=0, relu=0, accumulate=0,
                               out_mode=0, tile=tile % 100, x_planes=xp.data_ptr() if pre else None, w_planes=wp.data_ptr() if (pre or wonly) else None,
-                              stats=None, w_frag_planes=fp.data_ptr() if (fp is not None and tile % 100 == 24) else None)
+                              stats=None, w_frag_planes=fp.data_ptr() if (fp is not None and tile % 100 == 24) else None,
+                              x_absmax=xmax.data_ptr() if (xmax is not None and tile % 100 == 24) else None)
             if L.qea_conv_igemm(C.byref(d), s) != 0:     # a forced tile that does not take this shape
                 print(f"H{H:3d} W{W:3d} Cin{Cin:4d} Cout{Cout:4d} tile{tile}   n/a", flush=True)
                 continue

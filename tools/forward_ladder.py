@@ -19,7 +19,7 @@ ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ladder.json")))
 out = {}
 for case in cases:
     fx = H.golden(case)
-    for mode in ("split_bf16", "f32"):
+    for mode in ("split_f16", "split_bf16", "f32"):
         prev = ops.set_mfma_mode(mode)
         for ci in range(int(fx["n_candidates"])):
             r = cr.run_candidate(case, fx, f"c{ci}|")

@@ -26,17 +26,19 @@ def draw(kind, shape, g):
         x = x.clamp_min(0)
     if kind == "small":                        # gradient magnitudes of a mean-reduced loss
         x = x * 1e-5
+    if kind == "wide":                         # 12 decades of dynamic range inside one tensor
+        x = x * torch.exp(4 * torch.randn(shape, generator=g))
     return x
 
 
 for (B, H, W, Ci, Co) in SHAPES:
-    for kind in ("gauss", "sparse", "positive", "small"):
+    for kind in ("gauss", "sparse", "positive", "small", "wide"):
         g = torch.Generator().manual_seed(7)
         x = draw(kind, (B, H, W, Ci), g)
         w = torch.randn(Co, 3, 3, Ci, generator=g) / (9 * Ci) ** 0.5
         ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
         line = f"B{B} {H}x{W} {Ci}->{Co} {kind:9s}"
-        for mode in ("split_bf16", "f32"):
+        for mode in ("split_bf16", "split_f16", "f32"):
             prev = ops.set_mfma_mode(mode)
             y = torch.empty(B * H * W, Co, device="cuda")
             ops.conv_igemm(x.cuda(), w.cuda(), y, B=B, H=H, W=W, Cin=Ci, OH=H, OW=W, N=Co, KH=3, KW=3, pad=(1, 1), ldx=Ci, ldy=Co)
