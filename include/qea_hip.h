@@ -133,6 +133,9 @@ typedef struct qea_conv_desc {
    * Same accuracy class as the three-way bf16 split, half the matrix instructions, two thirds of the LDS.
    * NULL: the bf16 form. */
   const float* x_absmax;
+  /* ABI v6: zero-filled float slot receiving max |v| of the finite values this launch STORES (see qea_bn_apply's absmax_out);
+   * honoured by the LDS-halo kernel (tile 24) and by the generic split tiles 20-23 / 25 (incl. QEA_OUT_CONVT); NULL = off. */
+  float* y_absmax;
 } qea_conv_desc;
 
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
@@ -181,6 +184,11 @@ typedef struct qea_wgrad_desc {
   int32_t accumulate; /* dw += result                                                     */
   int32_t splits;     /* 0 = auto                                                         */
   int32_t tile;       /* 0 = auto                                                         */
+  /* ABI v6: when BOTH are non-NULL (device pointers to one float each: qea_absmax of p and of q) a launch that the nine-tap LDS-halo
+   * kernel takes (3x3 pad 1 stride 1, PW in {16, 32k}, R and C multiples of 32) runs the TWO-way fp16 split: three MFMAs per product
+   * instead of six (see qea_conv_desc.x_absmax).  Other launches ignore them. */
+  const float* p_absmax;
+  const float* q_absmax;
 } qea_wgrad_desc;
 
 size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d);
@@ -221,12 +229,16 @@ int qea_bn_train_stats_from_partials(const double* partials, int32_t blocks, int
 int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, const float* conv_bias, float* mean_out,
                       float* invstd_out, float* scale_out, float* shift_out, void* stream);
+/* absmax_out (ABI v6; here and in qea_bn_bwd / qea_maxpool_fwd / qea_maxpool_bwd; NULL = off): a zero-filled float slot into which the
+ * kernel folds max |v| of the finite values it stores (atomicMax on the bits) — the scale source of the two-way fp16 split for the
+ * conv / wgrad launch that consumes the tensor (qea_conv_desc.x_absmax, qea_wgrad_desc.p_absmax / q_absmax), carried by the
+ * producer instead of a qea_absmax pass.  Several launches may share one slot (per-group BatchNorm, the halves of a concat). */
 int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, int64_t M, int32_t C, const float* scale,
-                 const float* shift, int32_t relu, void* stream);
+                 const float* shift, int32_t relu, float* absmax_out, void* stream);
 int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* relu_scale,
                const float* relu_shift, const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* mean, const float* invstd, const double* stat64,
                int32_t training, float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy,
-               int32_t lddy, void* workspace, size_t workspace_bytes, void* stream);
+               int32_t lddy, void* workspace, size_t workspace_bytes, float* absmax_out, void* stream);
 /* out[c] (+)= sum_m x[m][c]  — conv / linear / LSTM bias gradients */
 int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, float* out, int32_t accumulate, void* workspace,
                size_t workspace_bytes, void* stream);
@@ -236,10 +248,10 @@ int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, float* out, in
  * arg-max from x; relu_mask additionally zeroes the gradient where the maximum is <= 0 (pool of
  * a ReLU output); accumulate: dx += (UNet skip connections). */
 int qea_maxpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C,
-                    int32_t kh, int32_t kw, void* stream);
+                    int32_t kh, int32_t kw, float* absmax_out, void* stream);
 int qea_maxpool_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B,
                     int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t relu_mask, int32_t accumulate,
-                    void* stream);
+                    float* absmax_out, void* stream);
 
 /* Filter re-layouts for the gradient GEMMs (run once per optimiser step):
  * out[c][r] = in[r][c];  wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]. */

@@ -107,6 +107,23 @@ __device__ __forceinline__ float qea_wave_max(float v) {
   return v;
 }
 
+// ---- abs-max carried by the PRODUCER of a tensor (round 3): the two-way fp16 split needs the largest finite magnitude of its
+// operands; a kernel that writes a tensor folds |v| of what it stores into a running maximum and commits it with one atomicMax
+// per wave (non-negative floats order like their bit patterns).  The caller zero-fills the 4-byte slot; several launches (a
+// BatchNorm applied per group, the two halves of a concat buffer) may share one slot.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ float qea_amax_acc(float m, float v) {
+  const float a = fabsf(v);
+  return (a <= 3.4028234663852886e38f && a > m) ? a : m;      // false for NaN; inf excluded
+}
+// every lane of the wave must reach this call (no early returns before it)
+__device__ __forceinline__ void qea_amax_commit(float m, float* out) {
+  if (!out) return;
+  m = qea_wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+#endif
+
 // event-bracketed timing of one kernel class (bench.py roofline leg)
 // QEA_MFMA=f32 keeps every product on v_mfma_f32_32x32x2_f32; anything else (default) allows the split-bf16 kernels
 bool qea_split_bf16_enabled();

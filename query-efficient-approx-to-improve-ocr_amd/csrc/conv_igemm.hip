@@ -35,6 +35,8 @@ struct ConvArgs {
   double* stats;
   // two-way fp16 split (QEA_MFMA_SPLIT_F16): largest finite |x| of the input tensor (device scalar) — the filter's is in its planes
   const float* xmax;
+  // producer-carried abs-max of the stored outputs (qea_conv_desc.y_absmax), or null
+  float* yamax;
 };
 
 // Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,
@@ -46,6 +48,7 @@ template <int MI, int NJ, int TM, int TN, bool STATS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&acc)[MI][NJ], int m0, int n0, int wm, int wn, int fr, int fh,
                                               int stats_block = 0) {
   const int ohw = p.OH * p.OW;
+  float am = 0.f;
   double st0[NJ], st1[NJ];
   if (STATS) {
 #pragma unroll
@@ -98,6 +101,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
         }
         if (p.accumulate) v += p.y[o];
         p.y[o] = v;
+        am = qea_amax_acc(am, v);
         if (STATS) {
           st0[j] += (double)v;
           st1[j] += (double)v * (double)v;
@@ -105,6 +109,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
       }
     }
   }
+  qea_amax_commit(am, p.yamax);                            // (every lane of the workgroup runs the epilogue to its end)
   if (STATS) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
                                                                int Ntot, const float* __restrict__ mask, int ldmask, int total,
-                                                               const float* __restrict__ xmax) {
+                                                               const float* __restrict__ xmax, float* __restrict__ yamax) {
   constexpr bool F16 = NPL == 2;
   typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
   constexpr bool SMALL = IMW != 0;
@@ -1242,6 +1247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int n = cur.nb * COUT + wn * 32 + fr;
     const float esc = scale ? scale[n] : 1.f, ebi = bias ? bias[n] : 0.f;
     double st0 = 0.0, st1 = 0.0;
+    float am = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -1265,12 +1271,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!live) continue;
         if (mask) v = (mask[prow * ldmask + n] > 0.f) ? v : 0.f;   // ReLU mask of another tensor (input gradient through a bare ReLU)
         y[prow * ldy + n] = v;
+        am = qea_amax_acc(am, v);
         if (STATS) {
           st0 += (double)v;
           st1 += (double)v * (double)v;
         }
       }
     }
+    qea_amax_commit(am, yamax);
     if (STATS) {                                        // one partial per (pixel tile, wave row): [blocks][Ntot][2]
       const double sa = st0 + __shfl_xor(st0, 32, 64);
       const double sc = st1 + __shfl_xor(st1, 32, 64);
@@ -1376,7 +1384,7 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
   // then both in their MFMA phase — and lose the overlap that staggered dispatch gives: 150-159 vs 159-166 TFLOP/s measured)
   const unsigned grid = (total > resident && COUT > 32) ? (unsigned)resident : (unsigned)total;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
-                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total, a.xmax);
+                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total, a.xmax, a.yamax);
   return QEA_OK;
 }
 
@@ -1554,6 +1562,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   a.KH = d->KH; a.KW = d->KW; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
   a.ldx = d->ldx; a.ldy = d->ldy; a.ldmask = d->ldmask; a.relu = d->relu; a.accumulate = d->accumulate; a.out_mode = d->out_mode;
   a.xmax = nullptr;
+  a.yamax = d->y_absmax;
   a.M = d->B * d->OH * d->OW;
   a.K = d->KH * d->KW * d->Cin;
   a.m_tiles = a.n_tiles = 0;

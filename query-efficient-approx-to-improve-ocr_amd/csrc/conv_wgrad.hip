@@ -17,6 +17,7 @@
 // Roofline: MFMA-bound for wide layers (2*M*R*taps*C flops), L2/HBM-leaning for the 32/64-
 // channel UNet levels where each pixel carries only 2*R*C*taps flops per (R+C)*4 bytes.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -785,17 +786,28 @@ constexpr int H9_HP_MAX = 136;   // halo pixels: (2+2) x (32+2) or (4+2) x (16+2
 
 // RB / CB = channel block of dY / X per workgroup (64, or 32 for the 32-channel level): 2x2 waves of 32x32 sub-blocks for
 // 64x64; with fewer sub-blocks the spare waves split the tile's four k-steps (WK = 4 / sub-blocks) and write separate slabs.
-template <int SW, int RB, int CB>
+// NPL = 3: three bf16 planes, six MFMAs per product.  NPL = 2 (round 3, ABI v6): two fp16 planes of the operands scaled by the
+// powers of two qea_f16_scale derives from their abs-max (pmax, qmax), three MFMAs per product (lh, hl, hh), two thirds of the LDS;
+// the block is un-scaled when it is written to its slab (exact).  The four registers a tap's fragments no longer need pay for
+// reading the X fragments one tap ahead in the 64 x 64 form too.
+template <int SW, int RB, int CB, int NPL = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ ws, int B, int H, int W, int R, int C,
-                            int ldp, int ldq, Halo9Plan hp) {
+                            int ldp, int ldq, Halo9Plan hp, const float* __restrict__ pmax, const float* __restrict__ qmax) {
+  constexpr bool F16 = NPL == 2;
+  typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
   constexpr int TH = 64 / SW, HW_ = SW + 2, HH = TH + 2, HP = HH * HW_;
   constexpr int WR = RB / 32, WC = CB / 32, WK = 4 / (WR * WC);
-  constexpr int P_PLANE = 64 * RB, Q_PLANE = H9_HP_MAX * CB;    // bf16 elements per plane
+  constexpr int P_PLANE = 64 * RB, Q_PLANE = H9_HP_MAX * CB;    // 16-bit elements per plane
   constexpr int RC4 = RB / 4, CC4 = CB / 4;                     // float4 chunks per pixel
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* Ps = reinterpret_cast<__bf16*>(smem);            // [3][64 px][RB ch]
-  __bf16* Qs = Ps + 3 * P_PLANE;                            // [3][HP_MAX px][CB ch]
+  __bf16* Ps = reinterpret_cast<__bf16*>(smem);            // [NPL][64 px][RB ch]
+  __bf16* Qs = Ps + NPL * P_PLANE;                          // [NPL][HP_MAX px][CB ch]
+  float sp = 1.f, sq = 1.f, inv_p = 1.f, inv_q = 1.f;
+  if constexpr (F16) {
+    qea_f16_scale(pmax[0], sp, inv_p);
+    qea_f16_scale(qmax[0], sq, inv_q);
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WR * WC), wrc = wave % (WR * WC);
@@ -852,24 +864,38 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
     for (int i = 0; i < NP; ++i) {
       const int e = tid + 256 * i;
       const int c4 = e % RC4, pix = e / RC4;
-      bf16x4 h, m, l;
-      qea_split3(preg[i], h, m, l);
       const int o = row_off(pix, c4, RB);
-      *reinterpret_cast<bf16x4*>(Ps + o) = h;
-      *reinterpret_cast<bf16x4*>(Ps + P_PLANE + o) = m;
-      *reinterpret_cast<bf16x4*>(Ps + 2 * P_PLANE + o) = l;
+      if constexpr (F16) {
+        f16x4 h, l;
+        qea_split2_f16(preg[i], sp, h, l);
+        *reinterpret_cast<f16x4*>(Ps + o) = h;
+        *reinterpret_cast<f16x4*>(Ps + P_PLANE + o) = l;
+      } else {
+        bf16x4 h, m, l;
+        qea_split3(preg[i], h, m, l);
+        *reinterpret_cast<bf16x4*>(Ps + o) = h;
+        *reinterpret_cast<bf16x4*>(Ps + P_PLANE + o) = m;
+        *reinterpret_cast<bf16x4*>(Ps + 2 * P_PLANE + o) = l;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int e = tid + 256 * i;
       const int c4 = e % CC4, hq = e / CC4;
       if (hq < HP) {
-        bf16x4 h, m, l;
-        qea_split3(qreg[i], h, m, l);
         const int o = row_off(hq, c4, CB);
-        *reinterpret_cast<bf16x4*>(Qs + o) = h;
-        *reinterpret_cast<bf16x4*>(Qs + Q_PLANE + o) = m;
-        *reinterpret_cast<bf16x4*>(Qs + 2 * Q_PLANE + o) = l;
+        if constexpr (F16) {
+          f16x4 h, l;
+          qea_split2_f16(qreg[i], sq, h, l);
+          *reinterpret_cast<f16x4*>(Qs + o) = h;
+          *reinterpret_cast<f16x4*>(Qs + Q_PLANE + o) = l;
+        } else {
+          bf16x4 h, m, l;
+          qea_split3(qreg[i], h, m, l);
+          *reinterpret_cast<bf16x4*>(Qs + o) = h;
+          *reinterpret_cast<bf16x4*>(Qs + Q_PLANE + o) = m;
+          *reinterpret_cast<bf16x4*>(Qs + 2 * Q_PLANE + o) = l;
+        }
       }
     }
   };
@@ -878,11 +904,26 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
   const int g16 = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
   const int l_pix = (g16 >> 1) * 8 + tq;
   const int l_ch = (g16 & 1) * 16 + tpp * 4;
-  auto frag_p = [&](const __bf16* plane, int pix) {          // pix = LDS pixel row of this lane's first 4-pixel block
-    return RB == 64 ? tr_frag(plane + pix * 64 + (((wr ^ (pix >> 1)) & 1) << 5) + l_ch, 64) : tr_frag(plane + pix * 32 + l_ch, 32);
+  auto frag_p = [&](const __bf16* plane, int pix) -> frag_t {   // pix = LDS pixel row of this lane's first 4-pixel block
+    return __builtin_bit_cast(frag_t, RB == 64 ? tr_frag(plane + pix * 64 + (((wr ^ (pix >> 1)) & 1) << 5) + l_ch, 64) : tr_frag(plane + pix * 32 + l_ch, 32));
   };
-  auto frag_q = [&](const __bf16* plane, int pix) {          // ((pix + 4) >> 1 has the parity of pix >> 1: both reads share the swap)
-    return CB == 64 ? tr_frag(plane + pix * 64 + (((wc ^ (pix >> 1)) & 1) << 5) + l_ch, 64) : tr_frag(plane + pix * 32 + l_ch, 32);
+  auto frag_q = [&](const __bf16* plane, int pix) -> frag_t {   // ((pix + 4) >> 1 has the parity of pix >> 1: both reads share the swap)
+    return __builtin_bit_cast(frag_t, CB == 64 ? tr_frag(plane + pix * 64 + (((wc ^ (pix >> 1)) & 1) << 5) + l_ch, 64) : tr_frag(plane + pix * 32 + l_ch, 32));
+  };
+  // the products of one tap: smallest terms first (the ll-class terms are dropped)
+  auto mma = [&](f32x16& a9, const frag_t* af, const frag_t* bf) {
+    if constexpr (F16) {
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[0], a9, 0, 0, 0);
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[1], a9, 0, 0, 0);
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], a9, 0, 0, 0);
+    } else {
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], a9, 0, 0, 0);
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], a9, 0, 0, 0);
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], a9, 0, 0, 0);
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], a9, 0, 0, 0);
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], a9, 0, 0, 0);
+      a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], a9, 0, 0, 0);
+    }
   };
 
   int tile = split;
@@ -896,36 +937,29 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
     for (int ks = wk; ks < 4; ks += WK) {                     // k-step = 16 consecutive pixels of one tile row (not unrolled: 144
                                                               // accumulator + prefetch registers leave no room for hoisted fragments)
       const int py = (ks * 16) / SW, px0 = (ks * 16) % SW;
-      bf16x8 af[3];
+      frag_t af[NPL];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) af[pl] = frag_p(Ps + pl * P_PLANE, ks * 16 + l_pix);
-      if constexpr (RB == 32) {
-        // (32-wide blocks only: the 64 x 64 variants have no registers to spare — there the second fragment set spills inside
-        // this loop: 512 x 512 249 -> 214 TFLOP/s, while the 32-wide blocks go 152 -> 169 and 172 -> 184)
-      // X fragments one tap ahead of their MFMAs: the six transposing reads of tap t + 1 are issued before the six MFMAs of tap t
-        // (read just in time, every tap started with an exposed LDS round trip)
-        auto read_q = [&](int t, bf16x8* bfr) {
+      for (int pl = 0; pl < NPL; ++pl) af[pl] = frag_p(Ps + pl * P_PLANE, ks * 16 + l_pix);
+      if constexpr (RB == 32 || F16) {
+        // X fragments one tap ahead of their MFMAs: the transposing reads of tap t + 1 are issued before the MFMAs of tap t (read
+        // just in time, every tap started with an exposed LDS round trip).  The 64 x 64 three-plane form has no registers for the
+        // second fragment set (it spills inside this loop: 512 x 512 249 -> 214 TFLOP/s; the 32-wide blocks go 152 -> 169 and
+        // 172 -> 184); the two-plane form has.
+        auto read_q = [&](int t, frag_t* bfr) {
           const int hq = (py + t / 3) * HW_ + px0 + t % 3 + l_pix;
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bfr[pl] = frag_q(Qs + pl * Q_PLANE, hq);
+          for (int pl = 0; pl < NPL; ++pl) bfr[pl] = frag_q(Qs + pl * Q_PLANE, hq);
         };
-        bf16x8 bq2[2][3];
+        frag_t bq2[2][NPL];
         read_q(0, bq2[0]);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const bf16x8* bf = bq2[t & 1];
+          const frag_t* bf = bq2[t & 1];
           if (t + 1 < 9) read_q(t + 1, bq2[(t + 1) & 1]);
-          f32x16& a9 = acc[t];
-          // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of wgrad_bf3_kernel
-          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], a9, 0, 0, 0);
-          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], a9, 0, 0, 0);
-          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], a9, 0, 0, 0);
-          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], a9, 0, 0, 0);
-          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], a9, 0, 0, 0);
-          a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], a9, 0, 0, 0);
+          mma(acc[t], af, bf);
           if (t + 1 < 9) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // the six LDS reads of tap t + 1 ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... ahead of the six MFMAs of tap t
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);          // the LDS reads of tap t + 1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 3 : 6, 0);      // ... ahead of the MFMAs of tap t
           }
         }
       } else {
@@ -934,17 +968,10 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             const int hq = (py + kh) * HW_ + px0 + kw + l_pix;
-            bf16x8 bf[3];
+            frag_t bf[NPL];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bf[pl] = frag_q(Qs + pl * Q_PLANE, hq);
-            f32x16& a9 = acc[kh * 3 + kw];
-            // smallest terms first (ll-class terms are dropped): lh, hl, mm, mh, hm, hh — the order of wgrad_bf3_kernel
-            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], a9, 0, 0, 0);
-            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], a9, 0, 0, 0);
-            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], a9, 0, 0, 0);
-            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], a9, 0, 0, 0);
-            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], a9, 0, 0, 0);
-            a9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], a9, 0, 0, 0);
+            for (int pl = 0; pl < NPL; ++pl) bf[pl] = frag_q(Qs + pl * Q_PLANE, hq);
+            mma(acc[kh * 3 + kw], af, bf);
           }
       }
     }
@@ -957,7 +984,7 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = r0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      out[((size_t)rr * 9 + t) * C + c0 + wc * 32 + fr] = acc[t][r];
+      out[((size_t)rr * 9 + t) * C + c0 + wc * 32 + fr] = F16 ? (acc[t][r] * inv_p) * inv_q : acc[t][r];
     }
 }
 
@@ -993,23 +1020,30 @@ Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
 // the 32- and 64-channel layers are taken by both halo kernels: the split-bf16 nine-tap form wins unless QEA_MFMA=f32
 bool prefer_halo9(const qea_wgrad_desc* d) { return qea_split_bf16_enabled() && halo9_plan(d).ok; }
 
-template <int SW, int RB, int CB>
+template <int SW, int RB, int CB, int NPL = 3>
 int launch_halo9_(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
-  constexpr size_t lds = (size_t)3 * (64 * RB + H9_HP_MAX * CB) * 2;
+  constexpr size_t lds = (size_t)NPL * (64 * RB + H9_HP_MAX * CB) * 2;
   const long long grid = (long long)h.r_blks * h.c_blks * h.splits;
-  auto kern = wgrad_halo9_bf3_kernel<SW, RB, CB>;
+  auto kern = wgrad_halo9_bf3_kernel<SW, RB, CB, NPL>;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr_rc != (int)hipSuccess) {
     qea_set_error("qea_conv_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString((hipError_t)attr_rc));
     return QEA_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h,
+                     d->p_absmax, d->q_absmax);
   return QEA_OK;
 }
 
+template <int SW, int RB, int CB>
+int launch_halo9_any(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
+  // both abs-max pointers given (ABI v6): the two-way fp16 split
+  return (d->p_absmax && d->q_absmax) ? launch_halo9_<SW, RB, CB, 2>(d, h, s) : launch_halo9_<SW, RB, CB, 3>(d, h, s);
+}
+
 int launch_halo9(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
-  if (h.sw == 32) return h.rb == 64 ? launch_halo9_<32, 64, 64>(d, h, s) : launch_halo9_<32, 32, 32>(d, h, s);
-  return h.rb == 64 ? launch_halo9_<16, 64, 64>(d, h, s) : launch_halo9_<16, 32, 32>(d, h, s);
+  if (h.sw == 32) return h.rb == 64 ? launch_halo9_any<32, 64, 64>(d, h, s) : launch_halo9_any<32, 32, 32>(d, h, s);
+  return h.rb == 64 ? launch_halo9_any<16, 64, 64>(d, h, s) : launch_halo9_any<16, 32, 32>(d, h, s);
 }
 
 }  // namespace

@@ -210,9 +210,10 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, 
 
 // ------------------------------------------------------------------ elementwise
 __global__ void bn_apply_kernel(const float* __restrict__ y, int ldy, float* __restrict__ a, int lda, long long M, int C,
-                                const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+                                const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ amax) {
   const int cols = C / 4;
   const long long n = M * cols;
+  float am = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / cols;
     const int ct = (int)(i - r * cols);
@@ -224,9 +225,11 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, int ldy, float* __r
     for (int k = 0; k < 4; ++k) {
       o[k] = bn_affine(v[k], sc[k], sh[k]);
       if (relu) o[k] = fmaxf(o[k], 0.f);
+      am = qea_amax_acc(am, o[k]);
     }
     *reinterpret_cast<f32x4*>(a + r * lda + ct * 4) = o;
   }
+  qea_amax_commit(am, amax);
 }
 
 __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ a, int lda,
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* 
                                                                     long long M, int C, const float* __restrict__ msc,
                                                                     const float* __restrict__ msh, const double* __restrict__ k0,
                                                                     const double* __restrict__ k1, const double* __restrict__ k2,
-                                                                    int rows_per_block, int rt_n) {
+                                                                    int rows_per_block, int rt_n, float* __restrict__ amax) {
   // dy = k0*dz + k1*y + k2 in fp64 with fp64 per-channel constants: mean(dz), mean(dz*xhat), mean and invstd are
   // common to all pixels of a channel, so rounding them to fp32 puts a CORRELATED error into dy which the
   // per-channel sums of the next layer amplify by the pixel count (measured 7e-4 on dbeta at M = 8192); ATen's
@@ -242,7 +245,8 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* 
   // registers) and walks rows, two per iteration to keep more bytes in flight.
   const int cols = C / 4;
   const int ct = threadIdx.x % cols, rt = threadIdx.x / cols;
-  if (rt >= rt_n) return;
+  const bool idle = rt >= rt_n;                            // (no early return: every lane meets in qea_amax_commit)
+  float am = 0.f;
   double c0[4], c1[4], c2[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -267,11 +271,12 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* 
       if (a) d = av[k] > 0.f ? d : 0.f;
       else if (remask) d = bn_affine(yv[k], sc[k], sh[k]) > 0.f ? d : 0.f;
       o[k] = (float)(c0[k] * (double)d + (c1[k] * (double)yv[k] + c2[k]));
+      am = qea_amax_acc(am, o[k]);
     }
     *reinterpret_cast<f32x4*>(dy + r * lddy + ct * 4) = o;
   };
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  long long r = r0 + rt;
+  long long r = idle ? r1 : r0 + rt;
   for (; r + rt_n < r1; r += 2 * rt_n) {
     const long long rb = r + rt_n;
     const f32x4 dza = *reinterpret_cast<const f32x4*>(da + r * ldda + ct * 4);
@@ -292,13 +297,15 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* 
     const f32x4 aa = a ? *reinterpret_cast<const f32x4*>(a + r * lda + ct * 4) : zero;
     one(r, dza, ya, aa);
   }
+  qea_amax_commit(am, amax);
 }
 
 // max-pool with window == stride (2x2 or 2x1), PyTorch tie rule: first maximum in (kh,kw) scan order
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C,
-                                   int kh, int kw) {
+                                   int kh, int kw, float* __restrict__ amax) {
   const int OH = H / kh, OW = W / kw, cols = C / 4;
   const long long n = (long long)B * OH * OW * cols;
+  float am = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int ct = (int)(i % cols);
     const long long op = i / cols;
@@ -314,13 +321,18 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* 
         for (int k = 0; k < 4; ++k) m[k] = (v[k] > m[k] || v[k] != v[k]) ? v[k] : m[k];
       }
     *reinterpret_cast<f32x4*>(y + op * ldy + ct * 4) = m;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) am = qea_amax_acc(am, m[k]);
   }
+  qea_amax_commit(am, amax);
 }
 
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, float* __restrict__ dx,
-                                   int lddx, int B, int H, int W, int C, int kh, int kw, int relu_mask, int accumulate) {
+                                   int lddx, int B, int H, int W, int C, int kh, int kw, int relu_mask, int accumulate,
+                                   float* __restrict__ amax) {
   const int OH = H / kh, OW = W / kw, cols = C / 4;
   const long long n = (long long)B * OH * OW * cols;
+  float am = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int ct = (int)(i % cols);
     const long long op = i / cols;
@@ -354,8 +366,11 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const f
         f32x4* dst = reinterpret_cast<f32x4*>(dx + ip * lddx + ct * 4);
         if (accumulate) o += *dst;
         *dst = o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) am = qea_amax_acc(am, o[k]);
       }
   }
+  qea_amax_commit(am, amax);
 }
 
 // out[c][r] = in[r][c]  (32x32 LDS tiles)
@@ -503,10 +518,10 @@ extern "C" int qea_bn_eval_coeff(int32_t C, const float* gamma, const float* bet
 }
 
 extern "C" int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, int64_t M, int32_t C, const float* scale,
-                            const float* shift, int32_t relu, void* stream) {
+                            const float* shift, int32_t relu, float* absmax_out, void* stream) {
   QEA_REQUIRE(y && a && scale && shift && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && lda % 4 == 0, "qea_bn_apply: bad arguments");
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, a, lda, (long long)M, C,
-                     scale, shift, relu);
+                     scale, shift, relu, absmax_out);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
@@ -514,7 +529,7 @@ extern "C" int qea_bn_apply(const float* y, int32_t ldy, float* a, int32_t lda, 
 extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const float* relu_scale, const float* relu_shift,
                           const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* mean, const float* invstd, const double* stat64, int32_t training,
                           float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          size_t workspace_bytes, float* absmax_out, void* stream) {
   QEA_REQUIRE(da && y && mean && invstd && dy, "qea_bn_bwd: null pointer");
   const ColGeom g = col_geom(M, C);
   int rc = check_nc("qea_bn_bwd", M, C, workspace_bytes, workspace, g);
@@ -540,7 +555,7 @@ extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t
   const int arows = (int)((M + agrid - 1) / agrid);
   agrid = (M + arows - 1) / arows;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)agrid), dim3(RED_THREADS), 0, s, da, ldda, a, lda, y, ldy, dy, lddy, (long long)M,
-                     C, relu_scale, relu_shift, (const double*)k0, (const double*)k1, (const double*)k2, arows, g.rt);
+                     C, relu_scale, relu_shift, (const double*)k0, (const double*)k1, (const double*)k2, arows, g.rt, absmax_out);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
@@ -562,23 +577,24 @@ extern "C" int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, flo
 }
 
 extern "C" int qea_maxpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t kh,
-                               int32_t kw, void* stream) {
+                               int32_t kw, float* absmax_out, void* stream) {
   QEA_REQUIRE(x && y && B > 0 && C > 0 && C % 4 == 0 && kh > 0 && kw > 0 && H % kh == 0 && W % kw == 0 && ldx % 4 == 0 && ldy % 4 == 0,
               "qea_maxpool_fwd: bad arguments (H,W must be multiples of the window; C, ld multiples of 4)");
   const long long n = (long long)B * (H / kh) * (W / kw) * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, kh, kw);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, kh, kw, absmax_out);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
 
 extern "C" int qea_maxpool_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B, int32_t H,
-                               int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t relu_mask, int32_t accumulate, void* stream) {
+                               int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t relu_mask, int32_t accumulate, float* absmax_out,
+                               void* stream) {
   QEA_REQUIRE(x && dy && dx && B > 0 && C > 0 && C % 4 == 0 && kh > 0 && kw > 0 && H % kh == 0 && W % kw == 0 && ldx % 4 == 0 &&
                   lddy % 4 == 0 && lddx % 4 == 0,
               "qea_maxpool_bwd: bad arguments");
   const long long n = (long long)B * (H / kh) * (W / kw) * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, dx, lddx, B, H, W, C, kh,
-                     kw, relu_mask, accumulate);
+                     kw, relu_mask, accumulate, absmax_out);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

@@ -47,35 +47,44 @@ class CRNNEngine:
             raise ValueError(f"batch {B} is not a multiple of groups={groups}")
         ctx = {"x": x, "B": B, "H": H, "W": W, "bn_training": bn_training, "groups": groups} if need_grad else None
 
+        # producer-carried abs-max of every tensor a split-fp16 conv / wgrad launch consumes (amx[name]; None when that split is off)
+        pool_ = ops.amax_pool(dev)
+        slot = (lambda: pool_.slot()) if pool_ is not None else (lambda: None)
+        amx = {}
         # conv1 (C_in = 1) + ReLU, pool 2x2
         a1 = torch.empty(B * H * W, 64, device=dev)
         ops.conv_c1_fwd(x, P[c + "conv1.weight"], P[c + "conv1.bias"], a1, 64, B, H, W, 64, relu=True)
         h, w = H // 2, W // 2
         p1 = torch.empty(B * h * w, 64, device=dev)
-        ops.maxpool_fwd(a1, 64, p1, 64, B, H, W, 64, 2, 2)
+        amx["p1"] = slot()
+        ops.maxpool_fwd(a1, 64, p1, 64, B, H, W, 64, 2, 2, amax=amx["p1"])
         acts = {"a1": a1, "p1": p1}
-        cur, ccur = p1, 64
+        cur, ccur, cur_name = p1, 64, "p1"
         dims = {"conv1": (H, W)}
         for name, cin, cout, relu, pool in CONVS:
             a = torch.empty(B * h * w, cout, device=dev)
+            amx["a" + name[-1]] = slot()
             ops.conv_igemm(cur, P[c + name + ".weight"], a, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1),
-                           ldx=cin, ldy=cout, bias=P[c + name + ".bias"], relu=relu, w_src=("fwd", P[c + name + ".weight"]))
+                           ldx=cin, ldy=cout, bias=P[c + name + ".bias"], relu=relu, w_src=("fwd", P[c + name + ".weight"]),
+                           x_amax=amx[cur_name], y_amax=amx["a" + name[-1]])
             acts["a" + name[-1]] = a
             dims[name] = (h, w)
-            cur, ccur = a, cout
+            cur, ccur, cur_name = a, cout, "a" + name[-1]
             if pool:
                 ph, pw = h // pool[0], w // pool[1]
                 pt = torch.empty(B * ph * pw, cout, device=dev)
-                ops.maxpool_fwd(a, cout, pt, cout, B, h, w, cout, pool[0], pool[1])
+                amx["p" + name[-1]] = slot()
+                ops.maxpool_fwd(a, cout, pt, cout, B, h, w, cout, pool[0], pool[1], amax=amx["p" + name[-1]])
                 acts["p" + name[-1]] = pt
-                cur = pt
+                cur, cur_name = pt, "p" + name[-1]
                 h, w = ph, pw
         # conv5 + BN1 + ReLU, conv6 + BN2 + ReLU (bias stays in the conv: y = conv + b is what BN sees)
         for name, bn, cin in (("conv5", "batchnorm1", 256), ("conv6", "batchnorm2", 512)):
             M = B * h * w
             y = torch.empty(M, 512, device=dev)
             ops.conv_igemm(cur, P[c + name + ".weight"], y, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=512, KH=3, KW=3, pad=(1, 1),
-                           ldx=cin, ldy=512, bias=P[c + name + ".bias"], w_src=("fwd", P[c + name + ".weight"]))
+                           ldx=cin, ldy=512, bias=P[c + name + ".bias"], w_src=("fwd", P[c + name + ".weight"]), x_amax=amx[cur_name])
+            amx["a" + name[-1]] = slot()
             G = groups if bn_training else 1
             Mg = M // G
             coef = torch.empty(G, 4, 512, device=dev)
@@ -90,10 +99,10 @@ class CRNNEngine:
                 else:
                     ops.bn_eval_coeff(512, P[c + bn + ".weight"], P[c + bn + ".bias"], Bf[c + bn + ".running_mean"],
                                       Bf[c + bn + ".running_var"], BN_EPS, None, coef[gi, 0], coef[gi, 1], coef[gi, 2], coef[gi, 3])
-                ops.bn_apply(yg, 512, ag, 512, Mg, 512, coef[gi, 2], coef[gi, 3], relu=True)
+                ops.bn_apply(yg, 512, ag, 512, Mg, 512, coef[gi, 2], coef[gi, 3], relu=True, amax=amx["a" + name[-1]])
             acts["y" + name[-1]], acts["coef" + name[-1]], acts["a" + name[-1]], acts["st" + name[-1]] = y, coef, a, stat64
             dims[name] = (h, w)
-            cur = a
+            cur, cur_name = a, "a" + name[-1]
         if bn_training:
             fs.ibuf.add_(groups)
         p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
@@ -136,7 +145,7 @@ class CRNNEngine:
         ops.log_softmax_fwd(logits, vp, lp, vp, T * B, self.vocab)
         out = lp.view(T, B, vp)[:, :, :self.vocab]
         if need_grad:
-            ctx.update(acts=acts, dims=dims, lstm=lstm, lp=lp, T=T, h6=h6, w6=w6)
+            ctx.update(acts=acts, dims=dims, lstm=lstm, lp=lp, T=T, h6=h6, w6=w6, amx=amx)
         return out, ctx
 
     # ------------------------------------------------------------------ backward
@@ -254,11 +263,15 @@ class CRNNEngine:
         da = torch.empty(B * h * w, 512, device=dev)
         ops.maxpool_bwd(acts["a6"], 512, dp6, 512, da, 512, B, h, w, 512, 2, 1, relu_mask=False)
         bn_training = ctx["bn_training"]
+        amx = ctx.get("amx", {})                                  # forward tensors' abs-max (a replica-group slice keeps its tensor's bound)
+        pool_ = ops.amax_pool(dev)
+        slot = (lambda: pool_.slot()) if pool_ is not None else (lambda: None)
         for name, bn, cin, src in (("conv6", "batchnorm2", 512, "a5"), ("conv5", "batchnorm1", 256, "p4")):
             M = B * h * w
             k = name[-1]
             coef = acts["coef" + k]
             dy_ = torch.empty(M, 512, device=dev)
+            dy_amax = slot()
             NG = coef.shape[0]
             Mg = M // NG
             for gi in range(NG):
@@ -267,43 +280,46 @@ class CRNNEngine:
                 ops.bn_bwd(da[sl], 512, None, 0, acts["y" + k][sl], 512, Mg, 512, P[c + bn + ".weight"], coef[gi, 0],
                            coef[gi, 1], bn_training, G[c + bn + ".weight"] if param_grads else None,
                            G[c + bn + ".bias"] if param_grads else None, dy_[sl], 512, accumulate=True,
-                           stat64=st[gi] if st is not None else None, relu_scale=coef[gi, 2], relu_shift=coef[gi, 3])
+                           stat64=st[gi] if st is not None else None, relu_scale=coef[gi, 2], relu_shift=coef[gi, 3], amax=dy_amax)
             if param_grads:
-                def bn_conv_grads(dy_=dy_, name=name, src=src, cin=cin, M=M):
+                def bn_conv_grads(dy_=dy_, name=name, src=src, cin=cin, M=M, dy_amax=dy_amax):
                     ops.colsum(dy_, 512, M, 512, G[c + name + ".bias"], accumulate=True)
                     ops.conv_wgrad(dy_, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=512, Cc=cin, KH=3, KW=3,
-                                   pad=(1, 1), ldp=512, ldq=cin, accumulate=True)
+                                   pad=(1, 1), ldp=512, ldq=cin, accumulate=True, p_amax=dy_amax, q_amax=amx.get(src))
                 side.run(bn_conv_grads, dy_)
             wt = ops.flip_transposed(P[c + name + ".weight"], 512, cin, 3, 3)
             da = torch.empty(M, cin, device=dev)
             ops.conv_igemm(dy_, wt, da, B=B, H=h, W=w, Cin=512, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=512, ldy=cin,
-                           w_src=("flipT", P[c + name + ".weight"]))
+                           w_src=("flipT", P[c + name + ".weight"]), x_amax=dy_amax)
         # da = grad of p4 [B,4,W/4,256]
         # conv4 (+ReLU, pool (2,1)), conv3 (+ReLU), conv2 (+ReLU, pool (2,2))
-        dcur = da
+        dcur, dcur_amax = da, None
         for name, cin, cout, relu, pool in reversed(CONVS):
             h, w = dims[name]
             M = B * h * w
             a = acts["a" + name[-1]]
             if pool:
                 dyc = torch.empty(M, cout, device=dev)
-                ops.maxpool_bwd(a, cout, dcur, cout, dyc, cout, B, h, w, cout, pool[0], pool[1], relu_mask=True)
+                dyc_amax = slot()
+                ops.maxpool_bwd(a, cout, dcur, cout, dyc, cout, B, h, w, cout, pool[0], pool[1], relu_mask=True, amax=dyc_amax)
             else:
-                dyc = dcur                                  # already masked by the producer's epilogue
+                dyc, dyc_amax = dcur, dcur_amax             # already masked by the producer's epilogue (which also left its abs-max)
             src = {"conv4": "a3", "conv3": "p2", "conv2": "p1"}[name]
             if param_grads:
-                def conv_grads(dyc=dyc, name=name, src=src, cin=cin, cout=cout, M=M, h=h, w=w):
+                def conv_grads(dyc=dyc, name=name, src=src, cin=cin, cout=cout, M=M, h=h, w=w, dyc_amax=dyc_amax):
                     ops.colsum(dyc, cout, M, cout, G[c + name + ".bias"], accumulate=True)
                     ops.conv_wgrad(dyc, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
-                                   pad=(1, 1), ldp=cout, ldq=cin, accumulate=True)
+                                   pad=(1, 1), ldp=cout, ldq=cin, accumulate=True, p_amax=dyc_amax, q_amax=amx.get(src))
                 side.run(conv_grads, dyc)
             wt = ops.flip_transposed(P[c + name + ".weight"], cout, cin, 3, 3)
             dnext = torch.empty(M, cin, device=dev)
             # conv4's input a3 is a bare ReLU output (no pool in between): fuse its mask here
             mask = acts["a3"] if name == "conv4" else None
+            dnext_amax = slot() if name == "conv4" else None   # conv4's input gradient IS conv3's output gradient (no pool in between)
             ops.conv_igemm(dyc, wt, dnext, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cin,
-                           mask=mask, ldmask=cin if mask is not None else 0, w_src=("flipT", P[c + name + ".weight"]))
-            dcur = dnext
+                           mask=mask, ldmask=cin if mask is not None else 0, w_src=("flipT", P[c + name + ".weight"]),
+                           x_amax=dyc_amax, y_amax=dnext_amax)
+            dcur, dcur_amax = dnext, dnext_amax
         # dcur = grad of p1 [B,16,W/2,64]; conv1
         dy1 = torch.empty(B * H * W, 64, device=dev)
         ops.maxpool_bwd(acts["a1"], 64, dcur, 64, dy1, 64, B, H, W, 64, 2, 2, relu_mask=True)

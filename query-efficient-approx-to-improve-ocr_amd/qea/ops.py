@@ -107,7 +107,7 @@ def transposed(w, R, Cc):
 
 def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(1, 1), ldx, ldy,
                scale=None, bias=None, mask=None, ldmask=0, relu=False, accumulate=False,
-               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None, want_stats=False):
+               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None, want_stats=False, x_amax=None, y_amax=None):
     """x_planes / w_planes: operands already in the P3 format (a caller that uses a tensor in several launches splits it
     once); when the launch runs on a split-bf16 tile and they are not given, they are made here (one HBM pass each).
     w_src = (kind, weight tensor): `w` is a function of that weight only (itself: kind "fwd"; its cached flip_transposed /
@@ -137,7 +137,8 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
         frag = weight_cached(("fragf16" if f16 else "frag", w_src[0], N, Cin), w_src[1], build) if w_src is not None else build()
         d.w_frag_planes = frag.data_ptr()
         if f16:
-            xmax = absmax(x, ldx, B * H * W, Cin)         # (v1: a pass of its own over the input; producers' epilogues can carry it)
+            # the input's abs-max: carried by the tensor's producer (x_amax), else one pass over the input here
+            xmax = x_amax if x_amax is not None else absmax(x, ldx, B * H * W, Cin)
             d.x_absmax = xmax.data_ptr()
     elif PRESPLIT["on"] and Cin % 16 == 0 and L.qea_conv_igemm_uses_split_bf16(C.byref(d)):
         K = KH * KW * Cin
@@ -153,6 +154,8 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
                     w_planes = split_planes(w, K, N, K)
             d.x_planes = x_planes.data_ptr() if x_planes is not None else None
             d.w_planes = w_planes.data_ptr()
+    if y_amax is not None:
+        d.y_absmax = y_amax.data_ptr()
     partials = None
     if want_stats and FUSE_BN_STATS["on"]:
         blocks = L.qea_conv_igemm_stats_blocks(C.byref(d))
@@ -164,12 +167,21 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
 
 
 def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride=(1, 1), ldp, ldq,
-               accumulate=False, splits=0, tile=0):
+               accumulate=False, splits=0, tile=0, p_amax=None, q_amax=None):
+    """p_amax / q_amax: device scalars holding the abs-max of p / q when the caller has them (the two-way fp16 split of the
+    nine-tap kernel needs both); in "split_f16" mode a missing one is computed here (one pass over the tensor)."""
     L = _lib.lib()
     d = _lib.WgradDesc(p=_ptr(p), q=_ptr(q), dw=_ptr(dw), workspace=None, workspace_bytes=0,
                        B=B, PH=PH, PW=PW, QH=QH, QW=QW, R=R, C=Cc, KH=KH, KW=KW, pad_h=pad[0], pad_w=pad[1],
                        stride_h=stride[0], stride_w=stride[1], ldp=ldp, ldq=ldq, accumulate=int(accumulate),
                        splits=splits, tile=tile)
+    if (SPLIT_F16["on"] and KH == 3 and KW == 3 and pad == (1, 1) and stride == (1, 1) and PH == QH and PW == QW and R % 32 == 0 and Cc % 32 == 0
+            and (PW % 32 == 0 or PW == 16) and tile in (0, 23) and mfma_mode() != "f32"):
+        if p_amax is None:
+            p_amax = absmax(p, ldp, B * PH * PW, R)
+        if q_amax is None:
+            q_amax = absmax(q, ldq, B * QH * QW, Cc)
+        d.p_absmax, d.q_absmax = p_amax.data_ptr(), q_amax.data_ptr()
     need = L.qea_conv_wgrad_workspace_bytes(C.byref(d))
     if need:
         ws = workspace(need, p.device)
@@ -199,6 +211,26 @@ def set_mfma_mode(mode):
 def mfma_mode():
     m = ("split_bf16", "f32")[_lib.lib().qea_set_mfma_mode(-1)]
     return "split_f16" if (m == "split_bf16" and SPLIT_F16["on"]) else m
+
+
+class AmaxPool:
+    """Zero-filled 4-byte slots for producer-carried abs-max values: one allocation + one memset per forward / backward pass."""
+
+    def __init__(self, device, n=192):
+        self.buf = torch.zeros(n, device=device)
+        self.used = 0
+
+    def slot(self):
+        if self.used == self.buf.numel():
+            self.buf = torch.zeros(self.buf.numel(), device=self.buf.device)
+            self.used = 0
+        self.used += 1
+        return self.buf[self.used - 1:self.used]
+
+
+def amax_pool(device):
+    """-> AmaxPool when the fp16 split is active (its launches want abs-max values), else None (producers then skip the atomics)"""
+    return AmaxPool(device) if (SPLIT_F16["on"] and mfma_mode() == "split_f16") else None
 
 
 def absmax(x, ld, M, Cc):
@@ -315,18 +347,20 @@ def bn_eval_coeff(C_, gamma, beta, running_mean, running_var, eps, conv_bias, me
                                             _stream()), "qea_bn_eval_coeff")
 
 
-def bn_apply(y, ldy, a, lda, M, C_, scale, shift, relu=True):
-    _lib.check(_lib.lib().qea_bn_apply(_ptr(y), ldy, _ptr(a), lda, M, C_, _ptr(scale), _ptr(shift), int(relu), _stream()),
+def bn_apply(y, ldy, a, lda, M, C_, scale, shift, relu=True, amax=None):
+    """amax (here and in bn_bwd / maxpool_fwd / maxpool_bwd / conv_igemm's y_amax): a zero-filled 1-element slot (AmaxPool) that receives
+    the abs-max of what the launch stores — the scale source of the fp16-split launch that consumes the tensor."""
+    _lib.check(_lib.lib().qea_bn_apply(_ptr(y), ldy, _ptr(a), lda, M, C_, _ptr(scale), _ptr(shift), int(relu), _ptr(amax), _stream()),
                "qea_bn_apply")
 
 
 def bn_bwd(da, ldda, a, lda, y, ldy, M, C_, gamma, mean, invstd, training, dgamma, dbeta, dy, lddy, accumulate=False, stat64=None,
-           relu_scale=None, relu_shift=None):
+           relu_scale=None, relu_shift=None, amax=None):
     """ReLU mask: pass the activation `a`, or a=None with the forward's scale/shift (mask recomputed from y, one tensor read less)."""
     wp, wn = _colws(M, C_, da.device)
     _lib.check(_lib.lib().qea_bn_bwd(_ptr(da), ldda, _ptr(a), lda, _ptr(relu_scale), _ptr(relu_shift), _ptr(y), ldy, M, C_, _ptr(gamma), _ptr(mean),
                                      _ptr(invstd), _ptr(stat64), int(training), _ptr(dgamma), _ptr(dbeta), int(accumulate),
-                                     _ptr(dy), lddy, wp, wn, _stream()), "qea_bn_bwd")
+                                     _ptr(dy), lddy, wp, wn, _ptr(amax), _stream()), "qea_bn_bwd")
 
 
 def colsum(x, ldx, M, C_, out, accumulate=False):
@@ -334,13 +368,13 @@ def colsum(x, ldx, M, C_, out, accumulate=False):
     _lib.check(_lib.lib().qea_colsum(_ptr(x), ldx, M, C_, _ptr(out), int(accumulate), wp, wn, _stream()), "qea_colsum")
 
 
-def maxpool_fwd(x, ldx, y, ldy, B, H, W, C_, kh, kw):
-    _lib.check(_lib.lib().qea_maxpool_fwd(_ptr(x), ldx, _ptr(y), ldy, B, H, W, C_, kh, kw, _stream()), "qea_maxpool_fwd")
+def maxpool_fwd(x, ldx, y, ldy, B, H, W, C_, kh, kw, amax=None):
+    _lib.check(_lib.lib().qea_maxpool_fwd(_ptr(x), ldx, _ptr(y), ldy, B, H, W, C_, kh, kw, _ptr(amax), _stream()), "qea_maxpool_fwd")
 
 
-def maxpool_bwd(x, ldx, dy, lddy, dx, lddx, B, H, W, C_, kh, kw, relu_mask=False, accumulate=False):
+def maxpool_bwd(x, ldx, dy, lddy, dx, lddx, B, H, W, C_, kh, kw, relu_mask=False, accumulate=False, amax=None):
     _lib.check(_lib.lib().qea_maxpool_bwd(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, B, H, W, C_, kh, kw,
-                                          int(relu_mask), int(accumulate), _stream()), "qea_maxpool_bwd")
+                                          int(relu_mask), int(accumulate), _ptr(amax), _stream()), "qea_maxpool_bwd")
 
 
 def transpose2d(src, dst, R, Cc):

@@ -50,7 +50,7 @@ class UNetEngine:
         Bf = dict(self.m.named_buffers())
         return P, Bf
 
-    def _conv_bn_relu(self, P, Bf, blk, i, x, ldx, cin, B, H, W, out, ldo, training, saved, groups=1):
+    def _conv_bn_relu(self, P, Bf, blk, i, x, ldx, cin, B, H, W, out, ldo, training, saved, groups=1, x_amax=None, out_amax=None):
         """x [B,H,W,cin] (pixel stride ldx) -> conv -> BN -> ReLU -> out (pixel stride ldo).
         groups > 1 (train mode): batch statistics per group of B / groups consecutive images, running statistics updated once
         per group in order — what `groups` sequential forward calls of the reference do (one document per call,
@@ -66,7 +66,7 @@ class UNetEngine:
             ops.bn_eval_coeff(cout, P[blk.key(i, "gamma")], P[blk.key(i, "beta")], Bf[blk.key(i, "rm")], Bf[blk.key(i, "rv")], BN_EPS,
                               None, coef[0], coef[1], coef[2], coef[3])
             ops.conv_igemm(x, w, out, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=ldo,
-                           scale=coef[2], bias=coef[3], relu=True, w_src=("fwd", w))
+                           scale=coef[2], bias=coef[3], relu=True, w_src=("fwd", w), x_amax=x_amax, y_amax=out_amax)
             return
         y = torch.empty(M, cout, device=dev)
         fused = None
@@ -76,7 +76,7 @@ class UNetEngine:
             # train-mode BatchNorm: the conv's epilogue also leaves per-block fp64 column sums of y (no second pass over y)
             # (per-group statistics take the separate pass: a statistics block of the generic tile may straddle two images)
             fused = ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=cout,
-                                   w_src=("fwd", w), want_stats=training and groups == 1)
+                                   w_src=("fwd", w), want_stats=training and groups == 1, x_amax=x_amax)
         gamma, beta = P[blk.key(i, "gamma")], P[blk.key(i, "beta")]
         rm, rv = Bf[blk.key(i, "rm")], Bf[blk.key(i, "rv")]
         if training and groups > 1:
@@ -87,7 +87,7 @@ class UNetEngine:
                 yg = y[g * Mg:(g + 1) * Mg]
                 ops.bn_train_stats(yg, cout, Mg, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[g, 0], coef[g, 1], coef[g, 2], coef[g, 3],
                                    stat64[g] if stat64 is not None else None)
-                ops.bn_apply(yg, cout, out[g * Mg:(g + 1) * Mg], ldo, Mg, cout, coef[g, 2], coef[g, 3], relu=True)
+                ops.bn_apply(yg, cout, out[g * Mg:(g + 1) * Mg], ldo, Mg, cout, coef[g, 2], coef[g, 3], relu=True, amax=out_amax)
             if saved is not None:
                 saved.append((y, coef, stat64))
             return
@@ -102,7 +102,7 @@ class UNetEngine:
                 ops.bn_train_stats(y, cout, M, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[0], coef[1], coef[2], coef[3], stat64)
         else:
             ops.bn_eval_coeff(cout, gamma, beta, rm, rv, BN_EPS, None, coef[0], coef[1], coef[2], coef[3])
-        ops.bn_apply(y, cout, out, ldo, M, cout, coef[2], coef[3], relu=True)
+        ops.bn_apply(y, cout, out, ldo, M, cout, coef[2], coef[3], relu=True, amax=out_amax)
         if saved is not None:
             saved.append((y, coef, stat64))
 
@@ -121,32 +121,39 @@ class UNetEngine:
             raise ValueError(f"batch {B} is not a multiple of bn_groups={groups}")
         ctx = {"x": x, "B": B, "H": H, "W": W, "training": training, "groups": groups, "blocks": {}} if need_grad else None
 
-        def run_block(blk, xin, ldx, cin, h, w, out, ldo):
+        # producer-carried abs-max slots of every tensor a split-fp16 conv / wgrad launch will consume (None: that split is off)
+        pool = ops.amax_pool(dev)
+        slot = (lambda: pool.slot()) if pool is not None else (lambda: None)
+
+        def run_block(blk, xin, ldx, cin, h, w, out, ldo, xin_amax, out_amax):
             saved = [] if need_grad else None
             a1 = torch.empty(B * h * w, blk.cout, device=dev)
-            self._conv_bn_relu(P, Bf, blk, 1, xin, ldx, cin, B, h, w, a1, blk.cout, training, saved, groups)
-            self._conv_bn_relu(P, Bf, blk, 2, a1, blk.cout, blk.cout, B, h, w, out, ldo, training, saved, groups)
+            a1_amax = slot()
+            self._conv_bn_relu(P, Bf, blk, 1, xin, ldx, cin, B, h, w, a1, blk.cout, training, saved, groups, xin_amax, a1_amax)
+            self._conv_bn_relu(P, Bf, blk, 2, a1, blk.cout, blk.cout, B, h, w, out, ldo, training, saved, groups, a1_amax, out_amax)
             if need_grad:
                 ctx["blocks"][blk.mod] = {"xin": xin, "ldx": ldx, "cin": cin, "h": h, "w": w, "a1": a1, "out": out, "ldo": ldo,
                                           "y1": saved[0][0], "coef1": saved[0][1], "st1": saved[0][2], "y2": saved[1][0],
-                                          "coef2": saved[1][1], "st2": saved[1][2]}
+                                          "coef2": saved[1][1], "st2": saved[1][2], "xin_amax": xin_amax, "a1_amax": a1_amax}
 
         # encoder: level l has c = f*2^(l-1) channels at (H,W)/2^(l-1); its output goes to cat_l[:, c:2c]
-        cats = {}
-        xin, ldx, cin = x, 1, 1
+        cats, cat_amax = {}, {}
+        xin, ldx, cin, xin_amax = x, 1, 1, None
         h, w = H, W
         for l, blk in enumerate(self.enc, start=1):
             c = blk.cout
             cat = torch.empty(B * h * w, 2 * c, device=dev)
             cats[l] = (cat, h, w, c)
+            cat_amax[l] = slot()                               # shared by the skip half (BatchNorm apply) and the up half (transposed conv)
             skip = cat[:, c:]
-            run_block(blk, xin, ldx, cin, h, w, skip, 2 * c)
+            run_block(blk, xin, ldx, cin, h, w, skip, 2 * c, xin_amax, cat_amax[l])
             pooled = torch.empty(B * (h // 2) * (w // 2), c, device=dev)
-            ops.maxpool_fwd(skip, 2 * c, pooled, c, B, h, w, c, 2, 2)
+            xin_amax = slot()
+            ops.maxpool_fwd(skip, 2 * c, pooled, c, B, h, w, c, 2, 2, amax=xin_amax)
             xin, ldx, cin = pooled, c, c
             h, w = h // 2, w // 2
         d = torch.empty(B * h * w, self.bott.cout, device=dev)
-        run_block(self.bott, xin, ldx, cin, h, w, d, self.bott.cout)
+        run_block(self.bott, xin, ldx, cin, h, w, d, self.bott.cout, xin_amax, None)
         dcin = self.bott.cout
         ups = {}
         for l in (4, 3, 2, 1):
@@ -154,11 +161,11 @@ class UNetEngine:
             wup = P[f"upconv{l}.weight"]                       # [2c][2][2][c] physical (IOHW channels_last)
             wT = ops.transposed(wup, dcin, 4 * c)
             ops.conv_igemm(d, wT, cat, B=B, H=h, W=w, Cin=dcin, OH=h, OW=w, N=4 * c, KH=1, KW=1, ldx=dcin, ldy=2 * c,
-                           bias=P[f"upconv{l}.bias"], out_mode=ops.OUT_CONVT, w_src=("T", wup))
+                           bias=P[f"upconv{l}.bias"], out_mode=ops.OUT_CONVT, w_src=("T", wup), y_amax=cat_amax[l])
             ups[l] = (d, dcin, h, w)
             h, w = hh, ww
             dnew = torch.empty(B * h * w, c, device=dev)
-            run_block(self.dec[l], cat, 2 * c, 2 * c, h, w, dnew, c)
+            run_block(self.dec[l], cat, 2 * c, 2 * c, h, w, dnew, c, cat_amax[l], None)
             d, dcin = dnew, c
         out = torch.empty(B, 1, H, W, device=dev)
         ops.head_fwd(d, f, P["conv.weight"], P["conv.bias"], out, B * H * W, f)
@@ -187,19 +194,21 @@ class UNetEngine:
             self._side = side
 
         NG = ctx.get("groups", 1)
+        pool = ops.amax_pool(dev)
+        slot = (lambda: pool.slot()) if pool is not None else (lambda: None)
 
-        def bn_bwd(da, ldda, y, coef, st, i, dy, M, cout, blk):
+        def bn_bwd(da, ldda, y, coef, st, i, dy, M, cout, blk, amax=None):
             """BatchNorm(+ReLU) backward of conv i of a block; per statistics group when the forward ran with bn_groups"""
             if coef.dim() == 2:
                 ops.bn_bwd(da, ldda, None, 0, y, cout, M, cout, P[blk.key(i, "gamma")], coef[0], coef[1], training, G[blk.key(i, "gamma")],
-                           G[blk.key(i, "beta")], dy, cout, accumulate=True, stat64=st, relu_scale=coef[2], relu_shift=coef[3])
+                           G[blk.key(i, "beta")], dy, cout, accumulate=True, stat64=st, relu_scale=coef[2], relu_shift=coef[3], amax=amax)
                 return
             Mg = M // NG
             for g in range(NG):
                 sl = slice(g * Mg, (g + 1) * Mg)
                 ops.bn_bwd(da[sl], ldda, None, 0, y[sl], cout, Mg, cout, P[blk.key(i, "gamma")], coef[g, 0], coef[g, 1], training,
                            G[blk.key(i, "gamma")], G[blk.key(i, "beta")], dy[sl], cout, accumulate=True,
-                           stat64=st[g] if st is not None else None, relu_scale=coef[g, 2], relu_shift=coef[g, 3])
+                           stat64=st[g] if st is not None else None, relu_scale=coef[g, 2], relu_shift=coef[g, 3], amax=amax)
 
         def block_bwd(blk, da2, ldda):
             """da2: grad w.r.t. the block output (pixel stride ldda).  Returns grad w.r.t. the block input
@@ -209,26 +218,27 @@ class UNetEngine:
             M = B * h * w
             dy2 = torch.empty(M, cout, device=dev)
             # ReLU mask recomputed from y with the forward's scale/shift: the activation is not re-read
-            bn_bwd(da2, ldda, s["y2"], s["coef2"], s["st2"], 2, dy2, M, cout, blk)
+            dy2_amax, dy1_amax = slot(), slot()
+            bn_bwd(da2, ldda, s["y2"], s["coef2"], s["st2"], 2, dy2, M, cout, blk, dy2_amax)
             w2 = P[blk.key(2, "w")]
             side.run(lambda: ops.conv_wgrad(dy2, s["a1"], G[blk.key(2, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cout, KH=3, KW=3,
-                                            pad=(1, 1), ldp=cout, ldq=cout, accumulate=True), dy2)
+                                            pad=(1, 1), ldp=cout, ldq=cout, accumulate=True, p_amax=dy2_amax, q_amax=s.get("a1_amax")), dy2)
             w2t = ops.flip_transposed(w2, cout, cout, 3, 3)
             da1 = torch.empty(M, cout, device=dev)
             ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout,
-                           w_src=("flipT", w2))
+                           w_src=("flipT", w2), x_amax=dy2_amax)
             dy1 = torch.empty(M, cout, device=dev)       # (dy2 may still be read by its wgrad on the side stream)
-            bn_bwd(da1, cout, s["y1"], s["coef1"], s["st1"], 1, dy1, M, cout, blk)
+            bn_bwd(da1, cout, s["y1"], s["coef1"], s["st1"], 1, dy1, M, cout, blk, dy1_amax)
             if cin == 1:
                 side.run(lambda: ops.conv_c1_wgrad(s["xin"], dy1, cout, G[blk.key(1, "w")], None, B, h, w, cout, accumulate=True), dy1)
                 return None
             side.run(lambda: ops.conv_wgrad(dy1, s["xin"], G[blk.key(1, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
-                                            pad=(1, 1), ldp=cout, ldq=s["ldx"], accumulate=True), dy1)
+                                            pad=(1, 1), ldp=cout, ldq=s["ldx"], accumulate=True, p_amax=dy1_amax, q_amax=s.get("xin_amax")), dy1)
             w1 = P[blk.key(1, "w")]
             w1t = ops.flip_transposed(w1, cout, cin, 3, 3)
             dxin = torch.empty(M, cin, device=dev)
             ops.conv_igemm(dy1, w1t, dxin, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cin,
-                           w_src=("flipT", w1))
+                           w_src=("flipT", w1), x_amax=dy1_amax)
             return dxin
 
         # head
