@@ -120,7 +120,13 @@ __device__ __forceinline__ float qea_amax_acc(float m, float v) {
 __device__ __forceinline__ void qea_amax_commit(float m, float* out) {
   if (!out) return;
   m = qea_wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+  // thousands of waves meet on ONE address: an atomic only when this wave would raise the value it can see (a stale read costs a
+  // redundant atomic, never a wrong result) — same-address atomics from every wave cost 0.1 ms per launch
+  if ((threadIdx.x & 63) == 0 && m > 0.f) {
+    unsigned* slot = reinterpret_cast<unsigned*>(out);
+    const unsigned mine = __float_as_uint(m);
+    if (mine > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mine);
+  }
 }
 #endif
 
