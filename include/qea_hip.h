@@ -131,7 +131,8 @@ typedef struct qea_conv_desc {
    * operands are scaled by powers of two into fp16's range and split into h + l (11 + 11 bits); a product is three
    * v_mfma_f32_32x32x16_f16 (lh, hl, hh) instead of six bf16 ones, the accumulators are un-scaled in the epilogue (exact).
    * Same accuracy class as the three-way bf16 split, half the matrix instructions, two thirds of the LDS.
-   * NULL: the bf16 form. */
+   * The hybrid tiles (20-23, 25 with w_planes and no x_planes) take the same switch: w_planes must then come from
+   * qea_split_planes_f16.  NULL: the bf16 form. */
   const float* x_absmax;
   /* ABI v6: zero-filled float slot receiving max |v| of the finite values this launch STORES (see qea_bn_apply's absmax_out);
    * honoured by the LDS-halo kernel (tile 24) and by the generic split tiles 20-23 / 25 (incl. QEA_OUT_CONVT); NULL = off. */
@@ -150,6 +151,11 @@ int qea_absmax(const float* x, int32_t ld, int64_t M, int32_t C, float* out, voi
  * qea_f16_scale derives from wmax[0] (= qea_absmax of the filter), followed by one float holding the inverse scale.
  * qea_pack_frag_planes_f16_bytes gives the buffer size. */
 size_t qea_pack_frag_planes_f16_bytes(int32_t N, int32_t Cin);
+/* ABI v6.  The row format of qea_split_planes with TWO fp16 planes per value, scaled by the power of two of xmax[0] (= qea_absmax of
+ * x), the 128-byte zero tail, then one float = the inverse scale: the filter operand (w_planes) of the hybrid tiles 20-23 / 25
+ * when qea_conv_desc.x_absmax is given. */
+size_t qea_split_planes_f16_bytes(int64_t M, int32_t C);
+int qea_split_planes_f16(const float* x, int32_t ld, int64_t M, int32_t C, const float* xmax, void* planes, void* stream);
 int qea_pack_frag_planes_f16(const float* w, int32_t N, int32_t Cin, const float* wmax, void* planes, void* stream);
 size_t qea_pack_frag_planes_bytes(int32_t N, int32_t Cin);
 int qea_pack_frag_planes(const float* w, int32_t N, int32_t Cin, void* planes, void* stream);
@@ -184,9 +190,9 @@ typedef struct qea_wgrad_desc {
   int32_t accumulate; /* dw += result                                                     */
   int32_t splits;     /* 0 = auto                                                         */
   int32_t tile;       /* 0 = auto                                                         */
-  /* ABI v6: when BOTH are non-NULL (device pointers to one float each: qea_absmax of p and of q) a launch that the nine-tap LDS-halo
-   * kernel takes (3x3 pad 1 stride 1, PW in {16, 32k}, R and C multiples of 32) runs the TWO-way fp16 split: three MFMAs per product
-   * instead of six (see qea_conv_desc.x_absmax).  Other launches ignore them. */
+  /* ABI v6: when BOTH are non-NULL (device pointers to one float each: qea_absmax of p and of q) a launch that runs on a split tile —
+   * the nine-tap LDS-halo kernel (3x3 pad 1 stride 1, PW in {16, 32k}, R and C multiples of 32) or tiles 20-22 — takes the TWO-way
+   * fp16 split: three MFMAs per product instead of six (see qea_conv_desc.x_absmax).  Other launches ignore them. */
   const float* p_absmax;
   const float* q_absmax;
 } qea_wgrad_desc;

@@ -608,6 +608,35 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   *reinterpret_cast<bf16x8*>(dst + 32) = l;
 }
 
+// the two-plane fp16 row format of the same tensor: [row][C/16][plane h, l][16 fp16] of x * s (s from xmax, qea_f16_scale), 128 zero
+// bytes, then one float = 1 / s
+__global__ void split_planes_f16_kernel(const float* __restrict__ x, int ld, long long M, int C, const float* __restrict__ xmax,
+                                        _Float16* __restrict__ planes) {
+  const int c8n = C >> 3;
+  const long long total = M * c8n;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float sx, inv;
+  qea_f16_scale(xmax[0], sx, inv);
+  if (e < 32) reinterpret_cast<float*>(planes + M * C * 2)[e] = 0.f;      // the 128-byte zero tail
+  if (e == 0) reinterpret_cast<float*>(planes + M * C * 2)[32] = inv;
+  if (e >= total) return;
+  const long long row = e / c8n;
+  const int c8 = (int)(e - row * c8n);
+  const float* src = x + row * ld + c8 * 8;
+  f16x4 h0, l0, h1, l1;
+  qea_split2_f16(*reinterpret_cast<const f32x4*>(src), sx, h0, l0);
+  qea_split2_f16(*reinterpret_cast<const f32x4*>(src + 4), sx, h1, l1);
+  f16x8 h, l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = h0[k]; h[k + 4] = h1[k];
+    l[k] = l0[k]; l[k + 4] = l1[k];
+  }
+  _Float16* dst = planes + ((row * (C >> 4) + (c8 >> 1)) * 2) * 16 + (c8 & 1) * 8;
+  *reinterpret_cast<f16x8*>(dst) = h;
+  *reinterpret_cast<f16x8*>(dst + 16) = l;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Hybrid: activations split on the fly (conv_igemm_bf3_kernel's gather), FILTER from pre-split planes by LDS-DMA
 // (conv_igemm_p3_kernel's path).  Pre-splitting an ACTIVATION costs a 10-byte-per-element HBM pass for a tensor that one
@@ -616,9 +645,14 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // of the staging work — a third of it on the 256x128 tile, two thirds on 128x256 — leaves the VALU for free.
 // Same LDS image and MFMA sequence as the other two kernels: bit-identical results.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool STATS>
+// NPL = 2 (round 3, ABI v6): the two-way fp16 split — activations scaled by the power of two of their abs-max (p.xmax) and split
+// h + l on the fly, filter planes in the two-plane row format of qea_split_planes_f16 (64 B per row and K chunk, its inverse scale
+// behind the zero tail), three MFMAs per product, accumulators un-scaled before the epilogue.
+template <int BM, int BN, int WGM, int WGN, bool STATS, int NPL = 3>
 __global__ __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(WGM * WGN == 8 ? 4 : 1)))
 void conv_igemm_bf3w_kernel(const ConvArgs p) {
+  constexpr bool F16 = NPL == 2;
+  typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
   constexpr int BK = 16;
   constexpr int NW = WGM * WGN;
   constexpr int NT = NW * 64;
@@ -628,13 +662,18 @@ void conv_igemm_bf3w_kernel(const ConvArgs p) {
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MI = TM / 32, NJ = TN / 32;
   constexpr int A_LD = BM / RPP;
-  constexpr int NB = 3 * BN / 32;
+  constexpr int NB = NPL * BN / 32;
   constexpr int IB = (NB + NW - 1) / NW;
   static_assert(BM % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem);  // [2][3][BM][ROWB]
-  __bf16* Bs = As + 2 * 3 * BM * ROWB;           // [2][3][BN][ROWB]
+  __bf16* As = reinterpret_cast<__bf16*>(smem);  // [2][NPL][BM][ROWB] (16-bit elements)
+  __bf16* Bs = As + 2 * NPL * BM * ROWB;         // [2][NPL][BN][ROWB]
+  float sx = 1.f, inv_x = 1.f, inv_w = 1.f;
+  if constexpr (F16) {
+    qea_f16_scale(p.xmax[0], sx, inv_x);
+    inv_w = reinterpret_cast<const float*>(p.wp + p.wp_zero + 128)[0];
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -657,40 +696,47 @@ void conv_igemm_bf3w_kernel(const ConvArgs p) {
     const int j = wave + NW * i;
     b_off[i] = -1;
     if (j < NB) {
-      const int rb = j / 3, plane = j - rb * 3;
+      const int rb = j / NPL, plane = j - rb * NPL;
       const int row = rb * 32 + l_row;
       const int hsrc = l_half ^ ((row >> 3) & 1);
       const int n = n0 + row;
-      if (n < p.N) b_off[i] = n * (p.K >> 4) * 96 + plane * 32 + hsrc * 16;
+      if (n < p.N) b_off[i] = n * (p.K >> 4) * (NPL * 32) + plane * 32 + hsrc * 16;
     }
   }
   char* const lds_b = reinterpret_cast<char*>(Bs);
   auto dma_b = [&](int kt, int buf) {
     const int cs = kt / ntaps;
     const int tap = kt - cs * ntaps;
-    const int dB = (tap * cslices + cs) * 96;
+    const int dB = (tap * cslices + cs) * (NPL * 32);
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
       const int j = wave + NW * i;
       if (j < NB) {
-        const int rb = j / 3, plane = j - rb * 3;
+        const int rb = j / NPL, plane = j - rb * NPL;
         const unsigned off = (b_off[i] >= 0) ? (unsigned)(b_off[i] + dB) : p.wp_zero;
-        char* dst = lds_b + ((buf * 3 + plane) * BN + rb * 32) * (ROWB * 2);
+        char* dst = lds_b + ((buf * NPL + plane) * BN + rb * 32) * (ROWB * 2);
         __builtin_amdgcn_global_load_lds((qea_glob_void*)(p.wp + off), (qea_lds_void*)dst, 16, 0, 0);
       }
     }
   };
   auto stage_a = [&](int buf) {
-    __bf16* a_dst = As + (size_t)buf * 3 * BM * ROWB;
+    __bf16* a_dst = As + (size_t)buf * NPL * BM * ROWB;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      bf16x4 h, m, l;
-      qea_split3(g.a_reg[i], h, m, l);
       const int ro = lrow + RPP * i;
       const int o = ro * ROWB + (((kc >> 1) ^ ((ro >> 3) & 1)) << 3) + (kc & 1) * 4;
-      *reinterpret_cast<bf16x4*>(a_dst + o) = h;
-      *reinterpret_cast<bf16x4*>(a_dst + BM * ROWB + o) = m;
-      *reinterpret_cast<bf16x4*>(a_dst + 2 * BM * ROWB + o) = l;
+      if constexpr (F16) {
+        f16x4 h, l;
+        qea_split2_f16(g.a_reg[i], sx, h, l);
+        *reinterpret_cast<f16x4*>(a_dst + o) = h;
+        *reinterpret_cast<f16x4*>(a_dst + BM * ROWB + o) = l;
+      } else {
+        bf16x4 h, m, l;
+        qea_split3(g.a_reg[i], h, m, l);
+        *reinterpret_cast<bf16x4*>(a_dst + o) = h;
+        *reinterpret_cast<bf16x4*>(a_dst + BM * ROWB + o) = m;
+        *reinterpret_cast<bf16x4*>(a_dst + 2 * BM * ROWB + o) = l;
+      }
     }
   };
 
@@ -714,40 +760,54 @@ void conv_igemm_bf3w_kernel(const ConvArgs p) {
       dma_b(kt + 1, cur ^ 1);
       g.fetch(p, kt + 1);
     }
-    const __bf16* a_src = As + (size_t)cur * 3 * BM * ROWB + (wm * TM + fr) * ROWB + hsw;
-    const __bf16* b_src = Bs + (size_t)cur * 3 * BN * ROWB + (wn * TN + fr) * ROWB + hsw;
-    bf16x8 af[3][MI], bf[3][NJ];
+    const __bf16* a_src = As + (size_t)cur * NPL * BM * ROWB + (wm * TM + fr) * ROWB + hsw;
+    const __bf16* b_src = Bs + (size_t)cur * NPL * BN * ROWB + (wn * TN + fr) * ROWB + hsw;
+    frag_t af[NPL][MI], bf[NPL][NJ];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(a_src + pl * BM * ROWB + i * 32 * ROWB);
+      for (int i = 0; i < MI; ++i) af[pl][i] = *reinterpret_cast<const frag_t*>(a_src + pl * BM * ROWB + i * 32 * ROWB);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(b_src + pl * BN * ROWB + j * 32 * ROWB);
+      for (int j = 0; j < NJ; ++j) bf[pl][j] = *reinterpret_cast<const frag_t*>(b_src + pl * BN * ROWB + j * 32 * ROWB);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        if constexpr (F16) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
       }
     if (kt + 1 < KT) stage_a(cur ^ 1);
     __syncthreads();
   }
+  if constexpr (F16) {                                      // un-scale: exact (powers of two)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * inv_x) * inv_w;
+  }
   conv_epilogue<MI, NJ, TM, TN, STATS>(p, acc, m0, n0, wm, wn, fr, fh, tile_m * WGM + wm);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool STATS>
+template <int BM, int BN, int WGM, int WGN, bool STATS, int NPL = 3>
 int launch_bf3w_(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.m_tiles = qea_cdiv(p.M, BM);
   p.n_tiles = qea_cdiv(p.N, BN);
-  const size_t lds = (size_t)2 * 3 * (BM + BN) * 16 * 2;
-  auto kern = conv_igemm_bf3w_kernel<BM, BN, WGM, WGN, STATS>;
+  const size_t lds = (size_t)2 * NPL * (BM + BN) * 16 * 2;
+  auto kern = conv_igemm_bf3w_kernel<BM, BN, WGM, WGN, STATS, NPL>;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr_rc != (int)hipSuccess) {
     qea_set_error("qea_conv_igemm: cannot reserve %zu bytes of LDS for the %dx%d tile: %s", lds, BM, BN, hipGetErrorString((hipError_t)attr_rc));
@@ -764,6 +824,8 @@ int launch_bf3w_(const ConvArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WGM, int WGN>
 int launch_bf3w(const ConvArgs& a, hipStream_t s) {
+  if (a.xmax)                                              // two-way fp16 split: fp16 filter planes + the input's abs-max (ABI v6)
+    return a.stats ? launch_bf3w_<BM, BN, WGM, WGN, true, 2>(a, s) : launch_bf3w_<BM, BN, WGM, WGN, false, 2>(a, s);
   return a.stats ? launch_bf3w_<BM, BN, WGM, WGN, true>(a, s) : launch_bf3w_<BM, BN, WGM, WGN, false>(a, s);
 }
 
@@ -1580,7 +1642,9 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   const bool p3 = tile >= 20 && d->x_planes && d->w_planes;
   const bool wp3 = tile >= 20 && !d->x_planes && d->w_planes;
   if (p3 || wp3) {
-    const unsigned long long xb = p3 ? (unsigned long long)d->B * d->H * d->W * d->Cin * 6 : 0, wb = (unsigned long long)d->N * a.K * 6;
+    const bool f16w = wp3 && d->x_absmax;                  // hybrid tile on the two-way fp16 split: two planes per value
+    const unsigned long long xb = p3 ? (unsigned long long)d->B * d->H * d->W * d->Cin * 6 : 0, wb = (unsigned long long)d->N * a.K * (f16w ? 4 : 6);
+    if (f16w) a.xmax = d->x_absmax;
     QEA_REQUIRE(d->Cin % 16 == 0 && xb + 128 < 0x7fffffffULL && wb + 128 < 0x7fffffffULL,
                 "qea_conv_igemm: pre-split operands need Cin %% 16 == 0 and planes below 2 GiB (%llu, %llu bytes)", xb, wb);
     QEA_REQUIRE(((uintptr_t)d->x_planes & 15) == 0 && ((uintptr_t)d->w_planes & 15) == 0, "qea_conv_igemm: planes must be 16-byte aligned");
@@ -1657,6 +1721,19 @@ extern "C" int qea_split_planes(const float* x, int32_t ld, int64_t M, int32_t C
   const long long blocks = (total + 255) / 256;
   QEA_REQUIRE(blocks < 0x7fffffffLL, "qea_split_planes: too large");
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (long long)M, C, (__bf16*)planes);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" size_t qea_split_planes_f16_bytes(int64_t M, int32_t C) { return (size_t)M * (size_t)C * 4 + 128 + 16; }
+
+extern "C" int qea_split_planes_f16(const float* x, int32_t ld, int64_t M, int32_t C, const float* xmax, void* planes, void* stream) {
+  QEA_REQUIRE(x && planes && xmax && M > 0 && C > 0 && C % 16 == 0 && ld >= C && ld % 4 == 0, "qea_split_planes_f16: bad arguments (C=%d must be a multiple of 16)", C);
+  QEA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 15) == 0, "qea_split_planes_f16: pointers must be 16-byte aligned");
+  const long long total = M * (C >> 3);
+  const long long blocks = (total + 255) / 256;
+  QEA_REQUIRE(blocks < 0x7fffffffLL, "qea_split_planes_f16: too large");
+  hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, (long long)M, C, xmax, (_Float16*)planes);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

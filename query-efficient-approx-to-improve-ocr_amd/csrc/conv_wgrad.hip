@@ -29,6 +29,8 @@ struct WgArgs {
   int M, chunk, splits, accumulate;
   int r_tiles, c_tiles, tiles;  // tiles = r_tiles * taps * c_tiles
   long long slab;               // floats per split slab (R*taps*C)
+  const float* pmax;            // abs-max of P / Q (two-way fp16 split, ABI v6) or null
+  const float* qmax;
 };
 
 constexpr int BKP_MAX = 32;
@@ -285,8 +287,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int row_stride) {
   return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int BR, int BC, int WR, int WC>
+// NPL = 2 (round 3, ABI v6): the two-way fp16 split — P and Q scaled by the powers of two of their abs-max (a.pmax / a.qmax),
+// three MFMAs per product, the block un-scaled when it is written (exact).
+template <int BR, int BC, int WR, int WC, int NPL = 3>
 __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
+  constexpr bool F16 = NPL == 2;
+  typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
   constexpr int BKP = 16;
   constexpr int TR = BR / WR, TCc = BC / WC;
   constexpr int MI = TR / 32, NJ = TCc / 32;
@@ -300,8 +306,13 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
   static_assert(WR * WC == 4 && P_LD >= 1 && Q_LD >= 1, "4 waves, at least one chunk per thread");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* Ps = reinterpret_cast<__bf16*>(smem);  // [2][3][BKP][PR]
-  __bf16* Qs = Ps + 2 * 3 * BKP * PR;            // [2][3][BKP][QR]
+  __bf16* Ps = reinterpret_cast<__bf16*>(smem);  // [2][NPL][BKP][PR] (16-bit elements)
+  __bf16* Qs = Ps + 2 * NPL * BKP * PR;          // [2][NPL][BKP][QR]
+  float sp = 1.f, sq = 1.f, inv_p = 1.f, inv_q = 1.f;
+  if constexpr (F16) {
+    qea_f16_scale(a.pmax[0], sp, inv_p);
+    qea_f16_scale(a.qmax[0], sq, inv_q);
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
@@ -321,28 +332,44 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
   g.init(a, tid, m_begin, m_end, r0, c0, kh, kw);
   auto gather = [&](int mbase) { g.fetch(a, mbase); };
   auto stage = [&](int buf) {
-    __bf16* pd = Ps + (size_t)buf * 3 * BKP * PR + g.grow * PR;
-    __bf16* qd = Qs + (size_t)buf * 3 * BKP * QR + g.grow * QR;
+    __bf16* pd = Ps + (size_t)buf * NPL * BKP * PR + g.grow * PR;
+    __bf16* qd = Qs + (size_t)buf * NPL * BKP * QR + g.grow * QR;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < P_LD; ++i) {
-      bf16x4 h, m, l;
-      qea_split3(((g.p_ok >> i) & 1) ? g.p_reg[i] : zero, h, m, l);
+      const f32x4 pv = ((g.p_ok >> i) & 1) ? g.p_reg[i] : zero;
       const int e0 = (g.gl + i * TPR) * 4;  // first channel of this chunk
       const int eo = SWP ? ((((e0 >> 5) ^ (g.grow & 3)) << 5) | (e0 & 31)) : e0;
-      *reinterpret_cast<bf16x4*>(pd + eo) = h;
-      *reinterpret_cast<bf16x4*>(pd + BKP * PR + eo) = m;
-      *reinterpret_cast<bf16x4*>(pd + 2 * BKP * PR + eo) = l;
+      if constexpr (F16) {
+        f16x4 h, l;
+        qea_split2_f16(pv, sp, h, l);
+        *reinterpret_cast<f16x4*>(pd + eo) = h;
+        *reinterpret_cast<f16x4*>(pd + BKP * PR + eo) = l;
+      } else {
+        bf16x4 h, m, l;
+        qea_split3(pv, h, m, l);
+        *reinterpret_cast<bf16x4*>(pd + eo) = h;
+        *reinterpret_cast<bf16x4*>(pd + BKP * PR + eo) = m;
+        *reinterpret_cast<bf16x4*>(pd + 2 * BKP * PR + eo) = l;
+      }
     }
 #pragma unroll
     for (int i = 0; i < Q_LD; ++i) {
-      bf16x4 h, m, l;
-      qea_split3(((g.q_ok >> i) & 1) ? g.q_reg[i] : zero, h, m, l);
+      const f32x4 qv = ((g.q_ok >> i) & 1) ? g.q_reg[i] : zero;
       const int e0 = (g.gl + i * TPR) * 4;
       const int eo = SWQ ? ((((e0 >> 5) ^ (g.grow & 3)) << 5) | (e0 & 31)) : e0;
-      *reinterpret_cast<bf16x4*>(qd + eo) = h;
-      *reinterpret_cast<bf16x4*>(qd + BKP * QR + eo) = m;
-      *reinterpret_cast<bf16x4*>(qd + 2 * BKP * QR + eo) = l;
+      if constexpr (F16) {
+        f16x4 h, l;
+        qea_split2_f16(qv, sq, h, l);
+        *reinterpret_cast<f16x4*>(qd + eo) = h;
+        *reinterpret_cast<f16x4*>(qd + BKP * QR + eo) = l;
+      } else {
+        bf16x4 h, m, l;
+        qea_split3(qv, h, m, l);
+        *reinterpret_cast<bf16x4*>(qd + eo) = h;
+        *reinterpret_cast<bf16x4*>(qd + BKP * QR + eo) = m;
+        *reinterpret_cast<bf16x4*>(qd + 2 * BKP * QR + eo) = l;
+      }
     }
   };
 
@@ -371,32 +398,38 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
   for (int st = 0; st < nstage; ++st) {
     const int cur = st & 1;
     if (st + 1 < nstage) gather(m_begin + (st + 1) * BKP);
-    const __bf16* ps = Ps + (size_t)cur * 3 * BKP * PR + t_row_p + t_col;
-    const __bf16* qs = Qs + (size_t)cur * 3 * BKP * QR + t_row_q + t_col;
-    bf16x8 af[3][MI], bf[3][NJ];
+    const __bf16* ps = Ps + (size_t)cur * NPL * BKP * PR + t_row_p + t_col;
+    const __bf16* qs = Qs + (size_t)cur * NPL * BKP * QR + t_row_q + t_col;
+    frag_t af[NPL][MI], bf[NPL][NJ];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int ch = (wr * TR) / 32 + i;  // 32-channel chunk of this tile
-        af[pl][i] = tr_frag(ps + pl * BKP * PR + ((SWP ? (ch ^ tq) : ch) << 5), PR);
+        af[pl][i] = __builtin_bit_cast(frag_t, tr_frag(ps + pl * BKP * PR + ((SWP ? (ch ^ tq) : ch) << 5), PR));
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int ch = (wc * TCc) / 32 + j;
-        bf[pl][j] = tr_frag(qs + pl * BKP * QR + ((SWQ ? (ch ^ tq) : ch) << 5), QR);
+        bf[pl][j] = __builtin_bit_cast(frag_t, tr_frag(qs + pl * BKP * QR + ((SWQ ? (ch ^ tq) : ch) << 5), QR));
       }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        if constexpr (F16) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
       }
     if (st + 1 < nstage) stage(cur ^ 1);
     __syncthreads();
@@ -414,7 +447,7 @@ __global__ __launch_bounds__(256) void wgrad_bf3_kernel(const WgArgs a) {
         const int cc = c0 + wc * TCc + j * 32 + fr;
         if (rr < a.R && cc < a.C) {
           const size_t o = (size_t)rr * ktot + tap * a.C + cc;
-          float v = acc[i][j][r];
+          float v = F16 ? (acc[i][j][r] * inv_p) * inv_q : acc[i][j][r];
           if (a.accumulate) v += outp[o];
           outp[o] = v;
         }
@@ -555,21 +588,27 @@ int slots_of() {
   return slots;
 }
 
-template <int BR, int BC>
+template <int BR, int BC, int NPL = 3>
 constexpr size_t lds_bytes_bf3() {
-  return (size_t)2 * 3 * 16 * ((BR >= 128 ? BR : BR + 32) + (BC >= 128 ? BC : BC + 32)) * 2;
+  return (size_t)2 * NPL * 16 * ((BR >= 128 ? BR : BR + 32) + (BC >= 128 ? BC : BC + 32)) * 2;
 }
 
-template <int BR, int BC, int WR, int WC>
-void launch_bf3(const WgArgs& a, hipStream_t s) {
-  constexpr size_t lds = lds_bytes_bf3<BR, BC>();
-  auto kern = wgrad_bf3_kernel<BR, BC, WR, WC>;
+template <int BR, int BC, int WR, int WC, int NPL>
+void launch_bf3_(const WgArgs& a, hipStream_t s) {
+  constexpr size_t lds = lds_bytes_bf3<BR, BC, NPL>();
+  auto kern = wgrad_bf3_kernel<BR, BC, WR, WC, NPL>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles * (unsigned)a.splits), dim3(256), lds, s, a);
+}
+
+template <int BR, int BC, int WR, int WC>
+void launch_bf3(const WgArgs& a, hipStream_t s) {
+  if (a.pmax && a.qmax) launch_bf3_<BR, BC, WR, WC, 2>(a, s);   // both abs-max values given: the two-way fp16 split
+  else launch_bf3_<BR, BC, WR, WC, 3>(a, s);
 }
 
 template <int BR, int BC, int WR, int WC>
@@ -1126,6 +1165,8 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
   a.slab = (long long)d->R * d->KH * d->KW * d->C;
   a.out = (p.splits > 1) ? (float*)d->workspace : d->dw;
   a.accumulate = (p.splits > 1) ? 0 : d->accumulate;
+  a.pmax = d->p_absmax;
+  a.qmax = d->q_absmax;
 
   hipStream_t s = (hipStream_t)stream;
   qea_prof_begin(QEA_PROF_CONV_WGRAD, s);

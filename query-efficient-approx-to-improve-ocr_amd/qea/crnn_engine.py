@@ -106,7 +106,8 @@ class CRNNEngine:
         if bn_training:
             fs.ibuf.add_(groups)
         p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
-        ops.maxpool_fwd(cur, 512, p6, 512, B, h, w, 512, 2, 1)
+        amx["p6"], amx["seq"] = slot(), slot()
+        ops.maxpool_fwd(cur, 512, p6, 512, B, h, w, 512, 2, 1, amax=amx["p6"])
         acts["p6"] = p6
         h6, w6 = h // 2, w
         T = w6 - 1
@@ -115,13 +116,16 @@ class CRNNEngine:
         # conv7 2x2 pad 0 -> [B,1,T,512], written as [T][B][512]
         seq = torch.empty(T, B, 512, device=dev)
         ops.conv_igemm(p6, P[c + "conv7.weight"], seq, B=B, H=h6, W=w6, Cin=512, OH=1, OW=T, N=512, KH=2, KW=2, ldx=512, ldy=512,
-                       bias=P[c + "conv7.bias"], out_mode=ops.OUT_TBC, w_src=("fwd", P[c + "conv7.weight"]))
+                       bias=P[c + "conv7.bias"], out_mode=ops.OUT_TBC, w_src=("fwd", P[c + "conv7.weight"]), x_amax=amx["p6"], y_amax=amx["seq"])
         dims["conv7"] = (h6, w6)
 
         # BiLSTM x2
         xin = seq
         lstm = []
         for layer in (0, 1):
+            # the layer input's abs-max for its two projection GEMMs: conv7 carried it for layer 0; the BiLSTM output of layer 0
+            # gets one pass of its own (shared by both directions)
+            xin_amax = amx["seq"] if layer == 0 else lstm[0]["y_amax"]
             gates = torch.empty(T, B, 2 * 4 * HID, device=dev)
             whf, whr = P[f"lstm.weight_hh_l{layer}"], P[f"lstm.weight_hh_l{layer}_reverse"]
 
@@ -130,17 +134,20 @@ class CRNNEngine:
                 bias = P[f"lstm.bias_ih_l{layer}{suf}"] + P[f"lstm.bias_hh_l{layer}{suf}"]
                 ops.conv_igemm(xin, P[f"lstm.weight_ih_l{layer}{suf}"], gates[:, :, d * 4 * HID:], B=1, H=1, W=T * B, Cin=512, OH=1,
                                OW=T * B, N=4 * HID, KH=1, KW=1, ldx=512, ldy=2 * 4 * HID, bias=bias,
-                               w_src=("fwd", P[f"lstm.weight_ih_l{layer}{suf}"]))
+                               w_src=("fwd", P[f"lstm.weight_ih_l{layer}{suf}"]), x_amax=xin_amax)
             cst = torch.empty(T, B, 2 * HID, device=dev)
             y = torch.empty(T, B, 2 * HID, device=dev)
             ops.lstm_layer_fwd_any(gates, cst, y, pf, split, T, B)
-            lstm.append({"x": xin, "gates": gates, "c": cst, "y": y, "pb": pb, "split": split})
+            # the layer output's abs-max (one pass): the next layer's projections / the Linear GEMM and, in the backward, the weight
+            # gradients that read y take it from here
+            y_amax = ops.absmax(y, 512, T * B, 512) if pool_ is not None else None
+            lstm.append({"x": xin, "gates": gates, "c": cst, "y": y, "pb": pb, "split": split, "x_amax": xin_amax, "y_amax": y_amax})
             xin = y
         # Linear + log_softmax (vocab padded to a multiple of 32 columns; pad columns stay 0)
         vp = self.vpad
         logits = torch.zeros(T * B, vp, device=dev)
         ops.conv_igemm(xin, P["linear.weight"], logits, B=1, H=1, W=T * B, Cin=512, OH=1, OW=T * B, N=self.vocab, KH=1, KW=1, ldx=512,
-                       ldy=vp, bias=P["linear.bias"], w_src=("fwd", P["linear.weight"]))
+                       ldy=vp, bias=P["linear.bias"], w_src=("fwd", P["linear.weight"]), x_amax=lstm[1]["y_amax"])
         lp = torch.zeros(T * B, vp, device=dev)
         ops.log_softmax_fwd(logits, vp, lp, vp, T * B, self.vocab)
         out = lp.view(T, B, vp)[:, :, :self.vocab]
@@ -175,13 +182,16 @@ class CRNNEngine:
         g = dlp.contiguous().view(TB, V)
         dlogits = torch.empty(TB, vp, device=dev)
         ops.log_softmax_bwd(g, V, ctx["lp"], vp, dlogits, vp, TB, V, vp, nan_scrub)
+        f16 = ops.amax_pool(dev) is not None                      # the split-fp16 GEMMs below want their operands' abs-max
+        dl_amax = ops.absmax(dlogits, vp, TB, vp) if f16 else None
 
         # Linear
         y1 = ctx["lstm"][1]["y"]
         if param_grads:
             def linear_grads():
                 dwl = torch.empty(vp, 512, device=dev)
-                ops.conv_wgrad(dlogits, y1, dwl, B=1, PH=1, PW=TB, QH=1, QW=TB, R=vp, Cc=512, KH=1, KW=1, ldp=vp, ldq=512)
+                ops.conv_wgrad(dlogits, y1, dwl, B=1, PH=1, PW=TB, QH=1, QW=TB, R=vp, Cc=512, KH=1, KW=1, ldp=vp, ldq=512,
+                               p_amax=dl_amax, q_amax=ctx["lstm"][1].get("y_amax"))
                 G["linear.weight"].add_(dwl[:V])
                 dbl = torch.empty(vp, device=dev)
                 ops.colsum(dlogits, vp, TB, vp, dbl)
@@ -197,7 +207,8 @@ class CRNNEngine:
             return out
         wlT = ops.weight_cached(("padT", vp), wlin, padded_T)
         dy = torch.empty(T, B, 512, device=dev)
-        ops.conv_igemm(dlogits, wlT, dy, B=1, H=1, W=TB, Cin=vp, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=vp, ldy=512, w_src=(("padT", vp), wlin))
+        ops.conv_igemm(dlogits, wlT, dy, B=1, H=1, W=TB, Cin=vp, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=vp, ldy=512, w_src=(("padT", vp), wlin),
+                       x_amax=dl_amax)
 
         # BiLSTM layers, top first
         dseq_bt = None
@@ -206,12 +217,15 @@ class CRNNEngine:
             gates, cst, yl, xin = s["gates"], s["c"], s["y"], s["x"]
             dc = torch.empty(B, 2 * HID, device=dev)
             ops.lstm_layer_bwd_any(gates, cst, dy, s["pb"], s["split"], dc, T, B)          # gates now hold dgates
+            # ONE abs-max pass over the gate gradients serves the four weight-gradient GEMMs and the input-gradient GEMM of the layer
+            # (a bound over both directions and all steps scales every slice of the tensor)
+            g_amax = ops.absmax(gates, 8 * HID, TB, 8 * HID) if f16 else None
             if param_grads:
-                def lstm_grads(layer=layer, gates=gates, xin=xin, yl=yl):
+                def lstm_grads(layer=layer, gates=gates, xin=xin, yl=yl, g_amax=g_amax, x_amax=s.get("x_amax"), y_amax=s.get("y_amax")):
                     for d, suf in enumerate(("", "_reverse")):
                         dg = gates[:, :, d * 4 * HID:]
                         ops.conv_wgrad(dg, xin, G[f"lstm.weight_ih_l{layer}{suf}"], B=1, PH=1, PW=TB, QH=1, QW=TB, R=4 * HID, Cc=512,
-                                       KH=1, KW=1, ldp=8 * HID, ldq=512, accumulate=True)
+                                       KH=1, KW=1, ldp=8 * HID, ldq=512, accumulate=True, p_amax=g_amax, q_amax=x_amax)
                         db = torch.empty(4 * HID, device=dev)                  # b_ih and b_hh enter the gates as a sum: one column
                         ops.colsum(dg, 8 * HID, TB, 4 * HID, db)               # sum (a full pass over the gate gradients) serves both
                         G[f"lstm.bias_ih_l{layer}{suf}"].add_(db)
@@ -223,7 +237,7 @@ class CRNNEngine:
                             else:
                                 pg, qh = gates[:T - 1, :, 4 * HID:], yl[1:, :, HID:]
                             ops.conv_wgrad(pg, qh, G[f"lstm.weight_hh_l{layer}{suf}"], B=1, PH=1, PW=n, QH=1, QW=n, R=4 * HID, Cc=HID,
-                                           KH=1, KW=1, ldp=8 * HID, ldq=2 * HID, accumulate=True)
+                                           KH=1, KW=1, ldp=8 * HID, ldq=2 * HID, accumulate=True, p_amax=g_amax, q_amax=y_amax)
                 side.run(lstm_grads)
             wf, wr = P[f"lstm.weight_ih_l{layer}"], P[f"lstm.weight_ih_l{layer}_reverse"]
 
@@ -233,17 +247,17 @@ class CRNNEngine:
                 ops.transpose2d(wcat, out, 8 * HID, 512)
                 return out
             wT = ops.weight_cached("catT", wf, cat_T, also=(wr,))
-            wT_planes = ops.weight_cached("catT_planes", wf, lambda wT=wT: ops.split_planes(wT, 8 * HID, 512, 8 * HID), also=(wr,))
             if layer == 1:
                 dxl = torch.empty(T, B, 512, device=dev)
                 ops.conv_igemm(gates, wT, dxl, B=1, H=1, W=TB, Cin=8 * HID, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512,
-                               w_planes=wT_planes)
+                               x_amax=g_amax, w_src=("catT", wf))      # (planes of the concatenated filter: cached with the forward weight, both change together)
                 dy = dxl
             else:
                 # rows (t,b) -> output row b*T + t : the gradient of conv7's output in its own [B,1,T,512] order
                 dseq_bt = torch.empty(B, T, 512, device=dev)
+                dseq_amax = ops.amax_pool(dev).slot() if f16 else None
                 ops.conv_igemm(gates, wT, dseq_bt, B=T, H=1, W=B, Cin=8 * HID, OH=1, OW=B, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512,
-                               out_mode=ops.OUT_TBC, w_planes=wT_planes)
+                               out_mode=ops.OUT_TBC, x_amax=g_amax, y_amax=dseq_amax, w_src=("catT", wf))
 
         # conv7 (2x2, pad 0) backward
         h6, w6 = ctx["h6"], ctx["w6"]
@@ -252,12 +266,12 @@ class CRNNEngine:
             def conv7_grads():
                 ops.colsum(dseq_bt, 512, B * T, 512, G[c + "conv7.bias"], accumulate=True)
                 ops.conv_wgrad(dseq_bt, p6, G[c + "conv7.weight"], B=B, PH=1, PW=T, QH=h6, QW=w6, R=512, Cc=512, KH=2, KW=2, ldp=512,
-                               ldq=512, accumulate=True)
+                               ldq=512, accumulate=True, p_amax=dseq_amax, q_amax=ctx.get("amx", {}).get("p6"))
             side.run(conv7_grads, dseq_bt)
         w7t = ops.flip_transposed(P[c + "conv7.weight"], 512, 512, 2, 2)
         dp6 = torch.empty(B * h6 * w6, 512, device=dev)
         ops.conv_igemm(dseq_bt, w7t, dp6, B=B, H=1, W=T, Cin=512, OH=h6, OW=w6, N=512, KH=2, KW=2, pad=(1, 1), ldx=512, ldy=512,
-                       w_src=("flipT", P[c + "conv7.weight"]))
+                       w_src=("flipT", P[c + "conv7.weight"]), x_amax=dseq_amax)
         # pool (2,1) backward -> grad of a6 (ReLU handled by bn_bwd's mask)
         h, w = dims["conv6"]
         da = torch.empty(B * h * w, 512, device=dev)

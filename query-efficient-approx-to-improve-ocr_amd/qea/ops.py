@@ -147,13 +147,15 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
             # launch, so it is only taken pre-split when the caller has the planes anyway (PRESPLIT["x"]: tools / tests)
             if x_planes is None and PRESPLIT.get("x") and B * H * W * Cin * 6 < (1 << 31) - 256:
                 x_planes = split_planes(x, ldx, B * H * W, Cin)
+            f16 = SPLIT_F16["on"] and x_planes is None and w_planes is None and N * K * 4 < (1 << 31) - 256
             if w_planes is None:
-                if w_src is not None:
-                    w_planes = weight_cached(("planes", w_src[0], N, K), w_src[1], lambda: split_planes(w, K, N, K))
-                else:
-                    w_planes = split_planes(w, K, N, K)
+                build = (lambda: split_planes_f16(w, K, N, K)) if f16 else (lambda: split_planes(w, K, N, K))
+                w_planes = weight_cached(("planesf16" if f16 else "planes", w_src[0], N, K), w_src[1], build) if w_src is not None else build()
             d.x_planes = x_planes.data_ptr() if x_planes is not None else None
             d.w_planes = w_planes.data_ptr()
+            if f16:                                       # hybrid tile on the two-way fp16 split: the activations' abs-max
+                xmax = x_amax if x_amax is not None else absmax(x, ldx, B * H * W, Cin)
+                d.x_absmax = xmax.data_ptr()
     if y_amax is not None:
         d.y_absmax = y_amax.data_ptr()
     partials = None
@@ -175,8 +177,10 @@ def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride
                        B=B, PH=PH, PW=PW, QH=QH, QW=QW, R=R, C=Cc, KH=KH, KW=KW, pad_h=pad[0], pad_w=pad[1],
                        stride_h=stride[0], stride_w=stride[1], ldp=ldp, ldq=ldq, accumulate=int(accumulate),
                        splits=splits, tile=tile)
-    if (SPLIT_F16["on"] and KH == 3 and KW == 3 and pad == (1, 1) and stride == (1, 1) and PH == QH and PW == QW and R % 32 == 0 and Cc % 32 == 0
-            and (PW % 32 == 0 or PW == 16) and tile in (0, 23) and mfma_mode() != "f32"):
+    nine_tap = (KH == 3 and KW == 3 and pad == (1, 1) and stride == (1, 1) and PH == QH and PW == QW and R % 32 == 0 and Cc % 32 == 0
+                and (PW % 32 == 0 or PW == 16) and tile in (0, 23))
+    generic_split = tile in (20, 21, 22) or (tile == 0 and ((R >= 128 and Cc >= 128) or (R >= 128 and Cc == 64) or (R == 64 and Cc >= 128)))
+    if SPLIT_F16["on"] and (nine_tap or generic_split) and mfma_mode() != "f32":
         if p_amax is None:
             p_amax = absmax(p, ldp, B * PH * PW, R)
         if q_amax is None:
@@ -231,6 +235,15 @@ class AmaxPool:
 def amax_pool(device):
     """-> AmaxPool when the fp16 split is active (its launches want abs-max values), else None (producers then skip the atomics)"""
     return AmaxPool(device) if (SPLIT_F16["on"] and mfma_mode() == "split_f16") else None
+
+
+def split_planes_f16(x, ld, M, Cc):
+    """the two-plane fp16 row format of a FILTER (qea_split_planes_f16), scaled by the power of two of its abs-max"""
+    L = _lib.lib()
+    out = torch.empty(L.qea_split_planes_f16_bytes(M, Cc), dtype=torch.uint8, device=x.device)
+    xmax = absmax(x, ld, M, Cc)
+    _lib.check(L.qea_split_planes_f16(_ptr(x), ld, M, Cc, _ptr(xmax), out.data_ptr(), _stream()), "qea_split_planes_f16")
+    return out
 
 
 def absmax(x, ld, M, Cc):

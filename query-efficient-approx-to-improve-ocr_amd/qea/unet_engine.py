@@ -153,7 +153,8 @@ class UNetEngine:
             xin, ldx, cin = pooled, c, c
             h, w = h // 2, w // 2
         d = torch.empty(B * h * w, self.bott.cout, device=dev)
-        run_block(self.bott, xin, ldx, cin, h, w, d, self.bott.cout, xin_amax, None)
+        d_amax = slot()                                        # the transposed conv that consumes d is a split GEMM too
+        run_block(self.bott, xin, ldx, cin, h, w, d, self.bott.cout, xin_amax, d_amax)
         dcin = self.bott.cout
         ups = {}
         for l in (4, 3, 2, 1):
@@ -161,11 +162,12 @@ class UNetEngine:
             wup = P[f"upconv{l}.weight"]                       # [2c][2][2][c] physical (IOHW channels_last)
             wT = ops.transposed(wup, dcin, 4 * c)
             ops.conv_igemm(d, wT, cat, B=B, H=h, W=w, Cin=dcin, OH=h, OW=w, N=4 * c, KH=1, KW=1, ldx=dcin, ldy=2 * c,
-                           bias=P[f"upconv{l}.bias"], out_mode=ops.OUT_CONVT, w_src=("T", wup), y_amax=cat_amax[l])
-            ups[l] = (d, dcin, h, w)
+                           bias=P[f"upconv{l}.bias"], out_mode=ops.OUT_CONVT, w_src=("T", wup), x_amax=d_amax, y_amax=cat_amax[l])
+            ups[l] = (d, dcin, h, w, d_amax)
             h, w = hh, ww
             dnew = torch.empty(B * h * w, c, device=dev)
-            run_block(self.dec[l], cat, 2 * c, 2 * c, h, w, dnew, c, cat_amax[l], None)
+            d_amax = slot()
+            run_block(self.dec[l], cat, 2 * c, 2 * c, h, w, dnew, c, cat_amax[l], d_amax)
             d, dcin = dnew, c
         out = torch.empty(B, 1, H, W, device=dev)
         ops.head_fwd(d, f, P["conv.weight"], P["conv.bias"], out, B * H * W, f)
@@ -210,6 +212,8 @@ class UNetEngine:
                            G[blk.key(i, "gamma")], G[blk.key(i, "beta")], dy[sl], cout, accumulate=True,
                            stat64=st[g] if st is not None else None, relu_scale=coef[g, 2], relu_shift=coef[g, 3], amax=amax)
 
+        last_amax = [None]                                        # abs-max slot of the tensor block_bwd returned last
+
         def block_bwd(blk, da2, ldda):
             """da2: grad w.r.t. the block output (pixel stride ldda).  Returns grad w.r.t. the block input
             as a fresh [M][cin] tensor, or None for the first encoder block."""
@@ -237,8 +241,9 @@ class UNetEngine:
             w1 = P[blk.key(1, "w")]
             w1t = ops.flip_transposed(w1, cout, cin, 3, 3)
             dxin = torch.empty(M, cin, device=dev)
+            last_amax[0] = slot()                               # a decoder block's input gradient feeds the transposed conv's dgrad GEMM
             ops.conv_igemm(dy1, w1t, dxin, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cin, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cin,
-                           w_src=("flipT", w1), x_amax=dy1_amax)
+                           w_src=("flipT", w1), x_amax=dy1_amax, y_amax=last_amax[0])
             return dxin
 
         # head
@@ -253,15 +258,16 @@ class UNetEngine:
             dcat = block_bwd(self.dec[l], dd, self.dec[l].cout)
             cat, hh, ww, c = ctx["cats"][l]
             dcats[l] = dcat
-            dprev, dcin, h, w = ctx["ups"][l]              # input of upconv_l: [B*h*w][dcin]
-            def up_grads(dcat=dcat, dprev=dprev, l=l, c=c, hh=hh, ww=ww, h=h, w=w, dcin=dcin):
+            dprev, dcin, h, w, dprev_amax = ctx["ups"][l]  # input of upconv_l: [B*h*w][dcin]
+            def up_grads(dcat=dcat, dprev=dprev, l=l, c=c, hh=hh, ww=ww, h=h, w=w, dcin=dcin, pa=dprev_amax, qa=last_amax[0]):
                 ops.colsum(dcat, 2 * c, B * hh * ww, c, G[f"upconv{l}.bias"], accumulate=True)
                 ops.conv_wgrad(dprev, dcat, G[f"upconv{l}.weight"], B=B, PH=h, PW=w, QH=hh, QW=ww, R=dcin, Cc=c, KH=2, KW=2,
-                               stride=(2, 2), ldp=dcin, ldq=2 * c, accumulate=True)
+                               stride=(2, 2), ldp=dcin, ldq=2 * c, accumulate=True, p_amax=pa, q_amax=qa)
             side.run(up_grads, dcat)
             dd = torch.empty(B * h * w, dcin, device=dev)
+            # (the GEMM reads the up half of dcat, whose abs-max the slot of the whole tensor bounds)
             ops.conv_igemm(dcat, P[f"upconv{l}.weight"], dd, B=B, H=hh, W=ww, Cin=c, OH=h, OW=w, N=dcin, KH=2, KW=2, stride=(2, 2),
-                           ldx=2 * c, ldy=dcin, w_src=("fwd", P[f"upconv{l}.weight"]))
+                           ldx=2 * c, ldy=dcin, w_src=("fwd", P[f"upconv{l}.weight"]), x_amax=last_amax[0])
         # bottleneck, then encoder 4..1: skip grad (dcat[:, c:]) + pool backward of the deeper level
         dpool = block_bwd(self.bott, dd, self.bott.cout)
         for l in (4, 3, 2, 1):

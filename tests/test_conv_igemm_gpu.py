@@ -138,6 +138,7 @@ def test_presplit_planes_bit_identical(tile, shape):
     bias = torch.randn(Cout, generator=g).cuda()
     OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     outs = []
+    prev_mode = ops.set_mfma_mode("split_bf16")                          # (the statement is about the three-way bf16 forms)
     for pre, prex in ((False, False), (True, False), (True, True)):       # split on the fly / filter planes (hybrid) / both operands
         ops.PRESPLIT["on"], ops.PRESPLIT["x"] = pre, prex
         try:
@@ -147,9 +148,16 @@ def test_presplit_planes_bit_identical(tile, shape):
             outs.append(y)
         finally:
             ops.PRESPLIT["on"], ops.PRESPLIT["x"] = True, False
+    ops.set_mfma_mode(prev_mode)
     torch.cuda.synchronize()
     assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[2]).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # the two-way fp16 form of the hybrid tile (default mode): same values to fp32 rounding, non-finite free
+    y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
+    ops.conv_igemm(x, w, y, B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW, N=Cout, KH=k, KW=k, pad=(pad, pad), stride=(stride, stride),
+                   ldx=Cin, ldy=Cout, bias=bias, relu=True, tile=tile)
+    assert torch.isfinite(y).all()
+    assert (y - outs[0]).abs().max().item() <= 2e-5 * max(1.0, outs[0].abs().max().item())
 
 
 def test_presplit_from_a_strided_concat_slice():
