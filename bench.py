@@ -47,6 +47,7 @@ FLOP_PER_IMG_FAITHFUL = 9.846e9      # 3 x 3.2819 GFLOP (dgrad +
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md, fp32-input MFMA (= vector peak)
 BF16_MFMA_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md, dense bf16 MFMA (256 CUs x 2048 MAC/clk x 2.4 GHz)
 SPLIT_BF16_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6   # fp32-equivalent: six bf16 MFMAs per fp32 multiply-add (h+m+l split)
+SPLIT_F16_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3    # fp32-equivalent: three fp16 MFMAs per fp32 multiply-add (scaled h+l split; fp16 dense peak = bf16's)
 
 
 def synth_batch(B, seed, device):
@@ -149,7 +150,8 @@ def cpu_baseline():
             "b128": b128, "b32": b32, "host": host}
 
 
-DOMINANT_KERNEL = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0>"
+DOMINANT_KERNEL = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 2>"
+DOMINANT_KERNEL_BF16 = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 3>"
 
 
 def source_hash():
@@ -403,7 +405,7 @@ def main():
         for k in list(prof):
             ops.prof_enable(k, False)
         # the single dominant kernel of the step (rocprofv3 lists it as conv3x3_halo_bf3_kernel<64, 128, 4, false>)
-        prof["dominant"] = ops.prof_read_tagged(ops.PROF_CONV_IGEMM, ops.prof_tag_halo_bf3(64, 128, False))
+        prof["dominant"] = ops.prof_read_tagged(ops.PROF_CONV_IGEMM, ops.prof_tag_halo_bf3(64, 128, False, f16=ops.mfma_mode() == "split_f16"))
         ops.set_overlap(overlap0)
         return prof, d, overlap0
 
@@ -416,6 +418,17 @@ def main():
             nsteps = max(2, min(args.steps, 4))
             nprof, ndt, _ = event_leg(main_step, nsteps)
             native = (nprof, ndt, nsteps)
+        finally:
+            ops.set_mfma_mode(prev)
+    bf16_leg = None
+    if not args.no_secondary and ops.mfma_mode() == "split_f16":
+        # the same steps in the round-2 form (three-way bf16 split, six MFMAs per product): the two forms on the same box
+        prev = ops.set_mfma_mode("split_bf16")
+        try:
+            nsteps = max(2, min(args.steps, 4))
+            main_step()
+            bprof, bdt, _ = event_leg(main_step, nsteps)
+            bf16_leg = (bprof, bdt, nsteps)
         finally:
             ops.set_mfma_mode(prev)
     no_cer = None
@@ -469,9 +482,13 @@ def main():
         dom_tf = tf(dom)
         # the class mixes split-bf16 launches (>= 128-channel layers) and native fp32-MFMA launches: its matrix roofline is
         # the flop-weighted harmonic blend of the two peaks (time at peak = flops_split / peak_split + flops_f32 / peak_f32)
-        blend = lambda q: 1.0 / ((q["flops_split_bf16"] / q["flops"]) / SPLIT_BF16_PEAK_TFLOPS
-                                 + (1.0 - q["flops_split_bf16"] / q["flops"]) / FP32_MFMA_PEAK_TFLOPS) if q["flops"] > 0 else FP32_MFMA_PEAK_TFLOPS
+        # time at peak = flops_f16 / peak_f16split + flops_bf16 / peak_bf16split + flops_fp32 / peak_fp32
+        blend = lambda q: 1.0 / ((q["flops_split_f16"] / q["flops"]) / SPLIT_F16_PEAK_TFLOPS + (q["flops_split_bf16"] / q["flops"]) / SPLIT_BF16_PEAK_TFLOPS
+                                 + (1.0 - (q["flops_split_bf16"] + q["flops_split_f16"]) / q["flops"]) / FP32_MFMA_PEAK_TFLOPS) if q["flops"] > 0 else FP32_MFMA_PEAK_TFLOPS
         f_split = ig["flops_split_bf16"] / ig["flops"] if ig["flops"] > 0 else 0.0
+        f_f16 = ig["flops_split_f16"] / ig["flops"] if ig["flops"] > 0 else 0.0
+        f16_mode = ops.mfma_mode() == "split_f16"
+        dom_peak = SPLIT_F16_PEAK_TFLOPS if f16_mode else SPLIT_BF16_PEAK_TFLOPS
         peak = blend(ig)
         imgs = B * world * args.steps
         workload = ("BASELINE configs[2]: full minibatch step of train_nn_area.py:212-287 — Phase A (UNet eval fwd, TopKCER k = 5 % of the "
@@ -487,7 +504,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if ops.mfma_mode() == "f32" else "f32 (>=128-channel GEMMs as 3 x bf16 split products, fp32 accumulate)",
+            "dtype": {"f32": "f32", "split_bf16": "f32 (GEMMs as 3 x bf16 split products, fp32 accumulate)",
+                      "split_f16": "f32 (GEMMs as scaled 2 x fp16 split products — three fp16 MFMAs per fp32 multiply-add — fp32 accumulate)"}[ops.mfma_mode()],
             "data": "synthetic",
             "overlap": {"wgrad_side_stream": overlap0, "ms_per_step_single_stream": dt_serial / args.steps * 1e3},
             "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * world, "full_step": not args.phase_b_only,
@@ -504,11 +522,13 @@ def main():
                         "end_to_end_tflops": FLOP_PER_IMG_FAITHFUL * imgs / dt_b / 1e12 if not args.skip_crnn_wgrad else None,
                         "note": "Phase B alone at the same batch: 9.846 GFLOP per image (SURVEY.md §8d unit of work)"},
             "roofline": {"bound": "mfma",
-                         "kernel": DOMINANT_KERNEL + " — the split-bf16 LDS-halo 3x3 convolution (conv_igemm.hip): fp32 operands as 3 bf16 "
-                                   "planes (input halo split once per tile in LDS, filter fragments pre-split), six v_mfma_f32_32x32x16_bf16 "
-                                   "per product, fp32 accumulate; forward and input gradient of every 3x3 layer with >= 64 input and >= 128 "
-                                   "output channels and W % 32 == 0",
-                         "achieved": dom_tf, "peak": SPLIT_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom_tf / SPLIT_BF16_PEAK_TFLOPS,
+                         "kernel": (DOMINANT_KERNEL if f16_mode else DOMINANT_KERNEL_BF16) + " — the LDS-halo 3x3 convolution (conv_igemm.hip): fp32 "
+                                   "operands scaled by the power of two of their abs-max and split into 2 fp16 planes (input halo split once per tile "
+                                   "in LDS, filter fragments pre-split), three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate [split_bf16 mode: "
+                                   "3 bf16 planes, six MFMAs]; forward and input gradient of every 3x3 layer with >= 64 input and >= 128 output "
+                                   "channels and W % 32 == 0",
+                         "achieved": dom_tf, "peak": dom_peak, "unit": "TFLOP/s", "frac": dom_tf / dom_peak,
+                         "frac_of_the_six_mfma_peak": dom_tf / SPLIT_BF16_PEAK_TFLOPS,
                          "avg_launch_us": dom["ms"] * 1e3 / max(1, dom["launches"]), "launches_per_step": dom["launches"] / args.steps,
                          "ms_per_step_in_kernel": dom["ms"] / args.steps, "share_of_step": dom["ms"] / args.steps / (dt_serial / args.steps * 1e3),
                          "algorithmic_flops_per_launch": dom["flops"] / max(1, dom["launches"]),
@@ -517,21 +537,24 @@ def main():
                          "measured": "HIP events around every launch of this kernel over the same K steps re-run with the wgrad side stream "
                                      f"disabled ({dt_serial / args.steps * 1e3:.2f} ms/step single-stream vs {dt / args.steps * 1e3:.2f} overlapped); "
                                      "avg_launch_us is comparable with profiles/r03_kernel_stats_b2048_single_stream.csv",
-                         "peak_is": f"bf16 dense MFMA peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} TFLOP/s fp32-equivalent",
+                         "peak_is": (f"fp16 dense MFMA peak / 3 = {SPLIT_F16_PEAK_TFLOPS:.1f} TFLOP/s fp32-equivalent (three MFMAs per product); rounds 1-2 priced "
+                                     f"the six-MFMA bf16 form against {SPLIT_BF16_PEAK_TFLOPS:.1f} (frac_of_the_six_mfma_peak)") if f16_mode else
+                                    f"bf16 dense MFMA peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} TFLOP/s fp32-equivalent",
                          "launch_class": {
                              "what": "all qea_conv_igemm launches (implicit-GEMM conv fwd/dgrad, convT, LSTM/linear GEMMs): the LDS-halo kernel above, "
                                      "conv_igemm_bf3w_kernel (other >= 128-channel GEMMs: pre-split filter planes by LDS-DMA), and the native "
                                      "v_mfma_f32_32x32x2_f32 kernels conv_igemm_kernel / conv3x3_halo_kernel",
                              "achieved": ach, "peak": peak, "frac": ach / peak, "traffic": traffic,
                              "algorithmic_bytes_per_launch": ig["bytes"] / max(1, ig["launches"]), "launches_per_step": ig["launches"] / args.steps,
-                             "ms_per_step_in_kernel": ig["ms"] / args.steps, "split_bf16_flop_fraction": f_split,
+                             "ms_per_step_in_kernel": ig["ms"] / args.steps, "split_bf16_flop_fraction": f_split, "split_f16_flop_fraction": f_f16,
                              "frac_of_native_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
-                             "peak_note": f"fp32-equivalent; flop-weighted blend of bf16 dense peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} "
-                                          f"({100 * f_split:.0f} % of the class's flops run split-bf16) and the fp32 MFMA peak "
+                             "peak_note": f"fp32-equivalent; flop-weighted blend of fp16 dense peak / 3 = {SPLIT_F16_PEAK_TFLOPS:.1f} ({100 * f_f16:.0f} % of the "
+                                          f"class's flops), bf16 dense peak / 6 = {SPLIT_BF16_PEAK_TFLOPS:.1f} ({100 * f_split:.0f} %) and the fp32 MFMA peak "
                                           f"{FP32_MFMA_PEAK_TFLOPS}"}},
             "kernels": {
                 "conv_wgrad": {"tflops": tf(wg), "ms_per_step": wg["ms"] / args.steps, "peak": blend(wg), "frac": tf(wg) / blend(wg),
                                "split_bf16_flop_fraction": wg["flops_split_bf16"] / wg["flops"] if wg["flops"] > 0 else 0.0,
+                               "split_f16_flop_fraction": wg["flops_split_f16"] / wg["flops"] if wg["flops"] > 0 else 0.0,
                                "algorithmic_bytes_per_launch": wg["bytes"] / max(1, wg["launches"]),
                                "launches_per_step": wg["launches"] / args.steps},
                 "lstm_step": {"tflops": tf(ls), "ms_per_step": ls["ms"] / args.steps, "launches_per_step": ls["launches"] / args.steps},
@@ -545,6 +568,14 @@ def main():
                 "conv_igemm_tflops": tf(nig), "peak": FP32_MFMA_PEAK_TFLOPS, "frac": tf(nig) / FP32_MFMA_PEAK_TFLOPS,
                 "conv_wgrad_tflops": tf(nwg), "conv_wgrad_frac": tf(nwg) / FP32_MFMA_PEAK_TFLOPS,
                 "ms_per_step_single_stream": ndt / nsteps * 1e3, "value": B * world * nsteps / ndt, "steps": nsteps}
+        if bf16_leg is not None:
+            bprof, bdt, nsteps = bf16_leg
+            big, bwg, bdom = bprof[ops.PROF_CONV_IGEMM], bprof[ops.PROF_CONV_WGRAD], bprof["dominant"]
+            out["roofline"]["split_bf16"] = {
+                "note": "the same steps with the round-2 three-way bf16 split (six MFMAs per product; QEA_SPLIT=bf16), single stream, HIP events",
+                "kernel": DOMINANT_KERNEL_BF16, "achieved": tf(bdom), "peak": SPLIT_BF16_PEAK_TFLOPS, "frac": tf(bdom) / SPLIT_BF16_PEAK_TFLOPS,
+                "avg_launch_us": bdom["ms"] * 1e3 / max(1, bdom["launches"]), "conv_igemm_tflops": tf(big), "conv_wgrad_tflops": tf(bwg),
+                "ms_per_step_single_stream": bdt / nsteps * 1e3, "value": B * world * nsteps / bdt, "steps": nsteps}
         if no_cer is not None:
             out["full_step_without_cer_update"] = no_cer
         if sel_first is not None:

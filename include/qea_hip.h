@@ -54,10 +54,13 @@ int qea_prof_read_launches(int klass, double* ms, double* flops, int64_t capacit
  * QEA_PROF_TAG_HALO_BF3(CIN, COUT, STATS) — the name rocprofv3 lists it under, so that bench.py's roofline figures of the
  * dominant kernel can be checked against the kernel trace. */
 #define QEA_PROF_TAG_HALO_BF3(cin_chunk, cout_group, stats) (24000 + ((cin_chunk) == 64 ? 1000 : 0) + (cout_group) + ((stats) ? 500 : 0))
+/* (+ 20 * image width for the small-image instantiations, + 5 for the two-way fp16 instantiation: each is its own kernel in a trace) */
 int qea_prof_read_tagged(int klass, int32_t tag, double* ms, double* flops, double* bytes, int64_t* launches);
 /* The part of a class's algorithmic flops that ran through the split-bf16 kernels (six bf16 MFMAs per fp32
  * multiply-add): bench.py blends the fp32 and the bf16/6 matrix peaks with it. */
 int qea_prof_read_split_bf16(int klass, double* flops);
+/* ABI v6: the part that ran through the two-way fp16 split (three fp16 MFMAs per fp32 multiply-add) */
+int qea_prof_read_split_f16(int klass, double* flops);
 
 /* Which matrix instruction the GEMM-class launches use: 0 = split-bf16 tiles where the dispatcher prefers them
  * (default), 1 = every product on v_mfma_f32_32x32x2_f32.  The initial value comes from QEA_MFMA=f32 in the

@@ -134,5 +134,6 @@ __device__ __forceinline__ void qea_amax_commit(float m, float* out) {
 // QEA_MFMA=f32 keeps every product on v_mfma_f32_32x32x2_f32; anything else (default) allows the split-bf16 kernels
 bool qea_split_bf16_enabled();
 void qea_prof_begin(int klass, hipStream_t s);
-void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool split_bf16 = false, int tag = 0);
+// split: 0 = fp32 MFMA, 1 = three-way bf16 split (six MFMAs per product), 2 = two-way fp16 split (three)
+void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, int split = 0, int tag = 0);
 void qea_prof_abort(int klass);

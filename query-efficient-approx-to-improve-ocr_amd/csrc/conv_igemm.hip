@@ -1696,7 +1696,7 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   // LDS-halo split kernel (its template instantiation), the tile id otherwise
   // (the small-image instantiations of the halo kernel are their own kernels in a trace: + 20 * image width)
   const int tag = tile == 24 ? QEA_PROF_TAG_HALO_BF3(d->Cin == 32 ? 32 : 64, d->N > 128 ? 128 : d->N, a.stats != nullptr) + 20 * halo_bf3_small(d) : tile;
-  qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20, tag);
+  qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20 ? (a.xmax ? 2 : 1) : 0, tag + (tile == 24 && a.xmax ? 5 : 0));
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

@@ -1143,7 +1143,8 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
       }
       reduce_slabs((float*)d->workspace, d->dw, (long long)slab / 4, h9.splits * h9.wk, d->accumulate, hs);
       qea_prof_end(QEA_PROF_CONV_WGRAD, hs, 2.0 * d->B * d->PH * (double)d->PW * (double)slab,
-                   4.0 * ((double)d->B * d->PH * d->PW * d->R + (double)d->B * d->QH * d->QW * d->C + (double)slab), true);
+                   4.0 * ((double)d->B * d->PH * d->PW * d->R + (double)d->B * d->QH * d->QW * d->C + (double)slab),
+                   (d->p_absmax && d->q_absmax) ? 2 : 1);
       QEA_CHECK_LAUNCH();
       return QEA_OK;
     }
@@ -1191,7 +1192,8 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
   }
   if (p.splits > 1) reduce_slabs((float*)d->workspace, d->dw, a.slab / 4, p.splits, d->accumulate, s);
   qea_prof_end(QEA_PROF_CONV_WGRAD, s, 2.0 * a.M * (double)a.slab,
-               4.0 * ((double)a.M * d->R + (double)d->B * d->QH * d->QW * d->C + (double)a.slab), p.tile >= 20);
+               4.0 * ((double)a.M * d->R + (double)d->B * d->QH * d->QW * d->C + (double)a.slab),
+               p.tile >= 20 ? ((a.pmax && a.qmax) ? 2 : 1) : 0);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

@@ -527,7 +527,7 @@ static int layer_fwd_impl(float* gates, float* c, float* y, const float* packed_
     int rc = QEA_OK;
     if (split) rc = launch_split_step<true>(p, B, s);
     else hipLaunchKernelGGL(kern, dim3(qea_cdiv(B, 32), HID / 32, 2), dim3(256), lds, s, p);
-    qea_prof_end(QEA_PROF_LSTM_STEP, s, step ? 2.0 * 2 * B * (double)GATES * HID : 0.0, 0.0, split);
+    qea_prof_end(QEA_PROF_LSTM_STEP, s, step ? 2.0 * 2 * B * (double)GATES * HID : 0.0, 0.0, split ? 1 : 0);
     if (rc != QEA_OK) return rc;
   }
   QEA_CHECK_LAUNCH();
@@ -585,7 +585,7 @@ static int layer_bwd_impl(float* gates, const float* c, const float* dy, const f
     int rc = QEA_OK;
     if (split) rc = launch_split_step<false>(p, B, s);
     else hipLaunchKernelGGL(kern, dim3(qea_cdiv(B, 32), HID / 32, 2), dim3(256), lds, s, p);
-    qea_prof_end(QEA_PROF_LSTM_STEP, s, k ? 2.0 * 2 * B * (double)GATES * HID : 0.0, 0.0, split);
+    qea_prof_end(QEA_PROF_LSTM_STEP, s, k ? 2.0 * 2 * B * (double)GATES * HID : 0.0, 0.0, split ? 1 : 0);
     if (rc != QEA_OK) return rc;
   }
   QEA_CHECK_LAUNCH();

@@ -14,7 +14,7 @@ struct ProfClass {
   bool on = false;
   std::vector<hipEvent_t> start, stop;  // event pool, reused across resets
   size_t used = 0;
-  double flops = 0.0, bytes = 0.0, flops_split = 0.0;  // flops_split: the part that ran as split-bf16 MFMAs
+  double flops = 0.0, bytes = 0.0, flops_split = 0.0, flops_f16 = 0.0;  // flops_split / flops_f16: the parts that ran as 3-way bf16 / 2-way fp16 split MFMAs
   std::vector<double> launch_flops, launch_bytes;
   std::vector<int> launch_tag;              // which kernel took the launch (class-specific code, 0 = unspecified)
   bool open = false;
@@ -65,7 +65,7 @@ void qea_prof_begin(int klass, hipStream_t s) {
   pc.open = true;
 }
 
-void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool split_bf16, int tag) {
+void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, int split, int tag) {
   ProfClass& pc = g_prof[klass];
   if (!pc.on || !pc.open) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -76,7 +76,8 @@ void qea_prof_end(int klass, hipStream_t s, double flops, double bytes, bool spl
   pc.launch_tag.push_back(tag);
   pc.flops += flops;
   pc.bytes += bytes;
-  if (split_bf16) pc.flops_split += flops;
+  if (split == 1) pc.flops_split += flops;
+  if (split == 2) pc.flops_f16 += flops;
   pc.open = false;
 }
 
@@ -101,7 +102,7 @@ extern "C" int qea_prof_reset(void) {
     pc.launch_flops.clear();
     pc.launch_bytes.clear();
     pc.launch_tag.clear();
-    pc.flops = pc.bytes = pc.flops_split = 0.0;
+    pc.flops = pc.bytes = pc.flops_split = pc.flops_f16 = 0.0;
     pc.open = false;
   }
   return QEA_OK;
@@ -151,6 +152,13 @@ extern "C" int qea_prof_read_tagged(int klass, int32_t tag, double* ms, double* 
   if (flops) *flops = fl;
   if (bytes) *bytes = by;
   if (launches) *launches = n;
+  return QEA_OK;
+}
+
+extern "C" int qea_prof_read_split_f16(int klass, double* flops) {
+  QEA_REQUIRE(klass >= 0 && klass < QEA_PROF_NCLASS && flops, "qea_prof_read_split_f16: bad arguments");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  *flops = g_prof[klass].flops_f16;
   return QEA_OK;
 }
 

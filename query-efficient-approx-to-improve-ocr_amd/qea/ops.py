@@ -316,14 +316,15 @@ def prof_reset():
 def prof_read(klass):
     ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
     _lib.check(_lib.lib().qea_prof_read(klass, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "qea_prof_read")
-    sp = C.c_double()
+    sp, sf = C.c_double(), C.c_double()
     _lib.check(_lib.lib().qea_prof_read_split_bf16(klass, C.byref(sp)), "qea_prof_read_split_bf16")
-    return {"ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value, "flops_split_bf16": sp.value}
+    _lib.check(_lib.lib().qea_prof_read_split_f16(klass, C.byref(sf)), "qea_prof_read_split_f16")
+    return {"ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value, "flops_split_bf16": sp.value, "flops_split_f16": sf.value}
 
 
-def prof_tag_halo_bf3(cin_chunk, cout_group, stats):
-    """QEA_PROF_TAG_HALO_BF3 of include/qea_hip.h"""
-    return 24000 + (1000 if cin_chunk == 64 else 0) + cout_group + (500 if stats else 0)
+def prof_tag_halo_bf3(cin_chunk, cout_group, stats, f16=False):
+    """QEA_PROF_TAG_HALO_BF3 of include/qea_hip.h (+ 5 for the two-way fp16 instantiation of the same kernel)"""
+    return 24000 + (1000 if cin_chunk == 64 else 0) + cout_group + (500 if stats else 0) + (5 if f16 else 0)
 
 
 def prof_read_tagged(klass, tag):
