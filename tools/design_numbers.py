@@ -1,5 +1,5 @@
 """Rewrites the 'Numbers of the final build' paragraph of DESIGN.md (and the cross-check line of profiles/README.md) from the
-committed profiles/r02_* files, so that the documents quote exactly what the files hold."""
+committed profiles/r03_* files, so that the documents quote exactly what the files hold."""
 import csv
 import json
 import os
@@ -7,53 +7,54 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda *a: os.path.join(ROOT, *a)
-DOM = "conv3x3_halo_bf3_kernel<64, 128, 4, false>"
+DOM = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 2>"
+WG = "wgrad_halo9_bf3_kernel<32, 64, 64, 2>"
+BEGIN, END = "<!-- numbers:begin -->", "<!-- numbers:end -->"
 
 
 def main():
-    d = json.loads(open(P("profiles", "r02_bench_b2048.json")).read().strip().splitlines()[-1])
-    u = json.loads(open(P("profiles", "r02_bench_b2048_under_rocprof_single_stream.json")).read().strip().splitlines()[-1])
-    tr = None
-    for row in csv.DictReader(open(P("profiles", "r02_kernel_stats_b2048_single_stream.csv"))):
+    d = json.loads(open(P("profiles", "r03_bench_b2048.json")).read().strip().splitlines()[-1])
+    u = json.loads(open(P("profiles", "r03_bench_b2048_under_rocprof_single_stream.json")).read().strip().splitlines()[-1])
+    tr, total = None, 0.0
+    for row in csv.DictReader(open(P("profiles", "r03_kernel_stats_b2048_single_stream.csv"))):
+        total += float(row["TotalDurationNs"])
         if DOM in row["Name"]:
             tr = (int(row["Calls"]), float(row["AverageNs"]) / 1e3)
-    t = json.load(open(P("profiles", "r02_pmc_traffic.json")))
-    m = json.load(open(P("profiles", "r02_pmc_mfma_busy.json")))["kernels"]
-    k0, k1 = m[DOM], m["wgrad_halo9_bf3_kernel<32, 64, 64>"]
+    t = json.load(open(P("profiles", "r03_pmc_traffic.json")))
+    m = json.load(open(P("profiles", "r03_pmc_mfma_busy.json")))["kernels"]
+    k0, k1 = m[DOM], m[WG]
     r = d["roofline"]
-    lc, wg, nf = r["launch_class"], d["kernels"]["conv_wgrad"], r["native_fp32"]
+    lc, wg, nf, bf = r["launch_class"], d["kernels"]["conv_wgrad"], r["native_fp32"], r["split_bf16"]
     kt = t["per_kernel_bytes_per_launch"][DOM]
     kb = kt["fetch"] + kt["write"]
-    nums = f'''Numbers of the final build (1× MI355X, `profiles/r02_bench_b2048.json`; the same build measured 150–156 ms on different
-boxes of the pool): **{d['value'] / 1e3:.2f} k patch-images/s for the full minibatch step at B = 2048** ({d['ms_per_step']:.1f} ms; {d['overlap']['ms_per_step_single_stream']:.1f} ms single-stream), of which
-Phase B alone is {d['phase_b']['ms_per_step']:.1f} ms = {d['phase_b']['value'] / 1e3:.2f} k img/s ({d['phase_b']['end_to_end_tflops']:.1f} TFLOP/s end to end on the reference-faithful 9.846 GFLOP/img); configs[1]
-(B = 512, Phase B) {d['configs1_b512']['value'] / 1e3:.2f} k img/s ({d['configs1_b512']['ms_per_step']:.1f} ms; round 1: 12.4 k); `--select_before_clean` {d['full_step_select_before_clean']['value'] / 1e3:.2f} k.
-`roofline` = the dominant kernel `{DOM}` ({100 * r['share_of_step']:.1f} % of the step, {r['launches_per_step']:.0f} launches/step): **{r['achieved']:.1f}
-TFLOP/s fp32-equivalent, `frac` {r['frac']:.3f}** of 419.4; average launch {r['avg_launch_us']:.1f} µs from bench.py's HIP events — the
-rocprofv3 trace of a run made of identical full steps gives {tr[1]:.1f} µs for the same kernel (`r02_kernel_stats_b2048_single_stream.csv`,
-{tr[0]} calls; the JSON line of that very run: {u['roofline']['avg_launch_us']:.1f}); HBM traffic {kb / 1e9:.2f} GB per launch against {r['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic ({kb / r['algorithmic_bytes_per_launch']:.2f}×: the halo
-overlap of neighbouring tiles plus filter fragments that spill the 4 MB L2 on the 512-channel layers and are re-fetched from the
-Infinity Cache / HBM). `roofline.launch_class` = all {lc['launches_per_step']:.0f} `qea_conv_igemm` launches of a step: {lc['achieved']:.1f} TFLOP/s, {lc['frac']:.3f} of the {lc['peak']:.1f}
-blend ({100 * lc['split_bf16_flop_fraction']:.1f} % of the flops split-bf16; round 1: 0.43), {lc['traffic'] / 1e9:.2f} GB of HBM traffic per launch against {lc['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic
-({lc['traffic'] / lc['algorithmic_bytes_per_launch']:.2f}×); Phase A's backward on the last replica's 103 samples adds small launches that pull this average down
-while shortening the step by 7 ms. `kernels.conv_wgrad`: {wg['tflops']:.1f} TFLOP/s over {wg['launches_per_step']:.0f} launches ({wg['ms_per_step']:.1f} ms), `frac` {wg['frac']:.3f} (0.45–0.47 over the
-round's runs), HBM {t['conv_wgrad']['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch against {wg['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic ({t['conv_wgrad']['hbm_bytes_per_launch'] / wg['algorithmic_bytes_per_launch']:.2f}×; 2.6× before the nine-tap kernel's workgroups of
-one pixel split were made XCD-contiguous; round 1: 2.6×). BiLSTM steps {d['kernels']['lstm_step']['ms_per_step']:.1f} ms (248 launches). Native-fp32 leg (`QEA_MFMA=f32`, same
-steps): conv class {nf['conv_igemm_tflops']:.1f} TFLOP/s = {nf['frac']:.3f} of 157.3, wgrad {nf['conv_wgrad_tflops']:.1f} = {nf['conv_wgrad_frac']:.3f}, {nf['value'] / 1e3:.2f} k img/s. `cpu_baseline`: {d['cpu_baseline']['value']:.1f} img/s at
-B = 128, {d['cpu_baseline']['b32']['value']:.1f} at B = 32 (16 threads of an EPYC 9575F box with 128 physical cores / 256 logical shared with the pool's other
-jobs; 54-60 / 90-118 over the round's runs). PMC (`r02_pmc_mfma_busy.json`, under the profiler): dominant kernel {k0['mfma_busy']} MFMA-busy at a
-held {k0['clock_ghz']} GHz, nine-tap wgrad {k1['mfma_busy']} at {k1['clock_ghz']} GHz, no LDS bank conflicts anywhere.
-'''
+    cb = d["cpu_baseline"]
+    nums = f'''{BEGIN}
+Numbers of the final build (1× MI355X, `profiles/r03_bench_b2048.json`): **{d['value'] / 1e3:.2f} k patch-images/s for the full minibatch step at
+B = 2048** ({d['ms_per_step']:.1f} ms incl. the CER update; {d['overlap']['ms_per_step_single_stream']:.1f} ms single-stream; {d['full_step_without_cer_update']['ms_per_step']:.1f} ms = {d['full_step_without_cer_update']['value'] / 1e3:.2f} k without the CER update, the round-2
+timed region, where round 2 measured 150.6 ms = 13.60 k), of which Phase B alone is {d['phase_b']['ms_per_step']:.1f} ms = {d['phase_b']['value'] / 1e3:.2f} k img/s ({d['phase_b']['end_to_end_tflops']:.1f} TFLOP/s end to end on the
+reference-faithful 9.846 GFLOP/img); configs[1] (B = 512, Phase B) {d['configs1_b512']['value'] / 1e3:.2f} k img/s ({d['configs1_b512']['ms_per_step']:.1f} ms); `--select_before_clean` {d['full_step_select_before_clean']['value'] / 1e3:.2f} k.
+The same steps on the same box in the other two arithmetic forms: three-way bf16 split (round 2's) {bf['value'] / 1e3:.2f} k img/s
+({bf['ms_per_step_single_stream']:.1f} ms single-stream; its dominant kernel {bf['achieved']:.1f} TFLOP/s = {bf['frac']:.3f} of 419.4), native fp32 MFMA {nf['value'] / 1e3:.2f} k (conv class {nf['conv_igemm_tflops']:.1f} TFLOP/s =
+{nf['frac']:.3f} of 157.3).
+`roofline` = the dominant kernel `{DOM}` ({100 * r['share_of_step']:.1f} % of the step, {r['launches_per_step']:.0f} launches/step): **{r['achieved']:.1f} TFLOP/s
+fp32-equivalent, `frac` {r['frac']:.3f}** of 838.9 (fp16 dense ÷ 3; {r['frac_of_the_six_mfma_peak']:.3f} of the 419.4 the six-MFMA form was priced against); average launch {r['avg_launch_us']:.1f} µs
+from bench.py's HIP events — the rocprofv3 trace of a run made of identical full steps gives {tr[1]:.1f} µs for the same kernel
+(`r03_kernel_stats_b2048_single_stream.csv`, {tr[0]} calls; the JSON line of that very run: {u['roofline']['avg_launch_us']:.1f}); HBM traffic {kb / 1e9:.2f} GB per launch against
+{r['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic ({kb / r['algorithmic_bytes_per_launch']:.2f}×). `roofline.launch_class` = all {lc['launches_per_step']:.0f} `qea_conv_igemm` launches of a step: {lc['achieved']:.1f} TFLOP/s, {lc['frac']:.3f} of the
+{lc['peak']:.1f} blend ({100 * lc['split_f16_flop_fraction']:.1f} % of the flops in the fp16 split), {t['conv_igemm']['hbm_bytes_per_launch'] / 1e9:.2f} GB of HBM traffic per launch against {lc['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic
+({t['conv_igemm']['hbm_bytes_per_launch'] / lc['algorithmic_bytes_per_launch']:.2f}×). `kernels.conv_wgrad`: {wg['tflops']:.1f} TFLOP/s over {wg['launches_per_step']:.0f} launches ({wg['ms_per_step']:.1f} ms; round 2: 188.6 TFLOP/s, 36.5 ms), `frac` {wg['frac']:.3f} of its
+{wg['peak']:.1f} blend, HBM {t['conv_wgrad']['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch against {wg['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic ({t['conv_wgrad']['hbm_bytes_per_launch'] / wg['algorithmic_bytes_per_launch']:.2f}×). BiLSTM steps {d['kernels']['lstm_step']['ms_per_step']:.1f} ms ({d['kernels']['lstm_step']['launches_per_step']:.0f} launches).
+`cpu_baseline`: {cb['value']:.1f} img/s at B = {cb['batch']} (B = 128: {cb['b128']['value']:.1f}; {cb['cores']} threads). PMC (`r03_pmc_mfma_busy.json`, under the profiler): dominant
+kernel {k0['mfma_busy']} MFMA-busy at a held {k0['clock_ghz']} GHz (the bf16 form: 0.72 at 1.89), nine-tap wgrad {k1['mfma_busy']} at {k1['clock_ghz']} GHz; sum of kernel time in the
+single-stream trace {total / 13e6:.1f} ms per step.
+{END}'''
     s = open(P("DESIGN.md")).read()
-    a = s.index("Numbers of the final build (1× MI355X, `profiles/r02_bench_b2048.json`")
-    b = s.index("Single-stream time by class (`r02_kernel_stats_b2048_single_stream.csv`)")
+    a, b = s.index(BEGIN), s.index(END) + len(END)
     s = s[:a] + nums + s[b:]
-    s = re.sub(r"\(`test_area_trainer_select_before_clean_is_the_same_training`\), [\d.]+ k vs [\d.]+ k img/s\.",
-               f"(`test_area_trainer_select_before_clean_is_the_same_training`), {d['full_step_select_before_clean']['value'] / 1e3:.2f} k vs {d['value'] / 1e3:.2f} k img/s.", s)
     open(P("DESIGN.md"), "w").write(s)
     s = open(P("profiles", "README.md")).read()
-    s = re.sub(r"`conv3x3_halo_bf3_kernel<64, 128, 4, false>` \d+ calls \(13 steps × 26\), average [\d.]+ µs in the trace against `roofline.avg_launch_us` = [\d.]+ µs",
-               f"`{DOM}` {tr[0]} calls (13 steps × 26), average {tr[1]:.1f} µs in the trace against `roofline.avg_launch_us` = {u['roofline']['avg_launch_us']:.1f} µs", s)
+    s = re.sub(r"CROSSCHECK[^|]*\|", f"`{DOM}` {tr[0]} calls (13 steps × 26), average {tr[1]:.1f} µs in the trace against `roofline.avg_launch_us` = "
+               f"{u['roofline']['avg_launch_us']:.1f} µs from bench.py's HIP events in the same run |", s, count=1)
     open(P("profiles", "README.md"), "w").write(s)
     print("ok", d["value"], r["frac"], tr, u["roofline"]["avg_launch_us"])
 
