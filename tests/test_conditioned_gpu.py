@@ -609,12 +609,12 @@ def test_document_patch_flow_vs_oracle(mfma_mode):
     """f2 (train_nn_patch.py:237-242,318-329; utils.py:118-141): UNet(train) on a whole [1,1,400,512] document -> crop+pad
     gather of the text strips -> CRNN(BN eval) -> CTC + scalar*MSE over the WHOLE page -> backward through the scatter-add
     into the document-sized gradient -> UNet backward; against the CPU oracle in fp64 under the HIP forward's decisions.
-    One image: the UNet's BN statistics are over 204 800 pixels per channel at level 1.  Loss 1e-4, every gradient tensor 1e-4 —
-    with one stated exception in the split-bf16 mode: a transposed conv's bias feeds a train-mode BatchNorm through a linear
-    conv, so its exact gradient is what is left at the image border of a sum over 51 200 .. 204 800 pixels whose interior cancels
-    (DESIGN.md §4).  The reference's own fp32 arithmetic reaches 5e-5 on these four tensors at this size, the native-fp32 mode
-    here 3e-5; the split form's pixel-correlated error component (bf16 MFMA alignment truncation, tools/micro/mfma_bias.hip,
-    tools/split_bias_probe.py) is amplified by the same cancellation to 1.2e-4.  They are held to 3e-4 in that mode."""
+    One image: the UNet's BN statistics are over 204 800 pixels per channel at level 1.  Loss 1e-4, every gradient tensor 1e-4 in the
+    default (two-way fp16 split: measured worst 6.8e-5) and the native-fp32 mode (2.5e-5) — with one stated exception in the three-way
+    bf16 split: a transposed conv's bias feeds a train-mode BatchNorm through a linear conv, so its exact gradient is what is left at the
+    image border of a sum over 51 200 .. 204 800 pixels whose interior cancels.  The reference's own fp32 arithmetic
+    reaches 5e-5 on these four tensors at this size; the bf16 form's pixel-correlated error component (bf16 MFMA alignment truncation,
+    tools/micro/mfma_bias.hip, tools/split_bias_probe.py) is amplified by the same cancellation to 1.2e-4: held to 3e-4 in that mode."""
     import decisions as D
     import utils
     from oracle import model_oracle as mo
@@ -660,7 +660,7 @@ def test_document_patch_flow_vs_oracle(mfma_mode):
     assert (crops.detach().cpu().double() - crops_r.detach()).abs().max().item() < 2e-6
     errs = {name: H.full_rel_err(p.grad, (Pu[name] if name in Pu else Pc[name]).grad)
             for name, p in list(prep.named_parameters()) + list(crnn.named_parameters())}
-    lim = (lambda k: DOC_CANCELLING.get(k, GATE)) if mfma_mode != "f32" else (lambda k: GATE)
+    lim = (lambda k: DOC_CANCELLING.get(k, GATE)) if mfma_mode == "split_bf16" else (lambda k: GATE)
     bad = {k: f"{v:.2e}" for k, v in errs.items() if not v <= lim(k)}
     assert not bad, bad
     print(f"\n[patch flow] [1,1,400,512] document, {n} strips, mode={mfma_mode}: worst full-tensor gradient error under the HIP decisions "
