@@ -23,10 +23,13 @@ def init_from_env(device=None):
         return world()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on these hosts
-    if device is not None and device.type == "cuda":
+    # QEA_DIST_BACKEND=gloo: rehearsal of the N-rank path on fewer GPUs than ranks (several ranks sharing one card, which RCCL
+    # refuses); gloo all-reduces / broadcasts CUDA tensors through the host, the CER all-gather already runs on CPU tensors then
+    backend = os.environ.get("QEA_DIST_BACKEND", "nccl" if (device is not None and device.type == "cuda") else "gloo")
+    if backend == "nccl":
         dist.init_process_group("nccl", device_id=device)
     else:
-        dist.init_process_group("gloo")
+        dist.init_process_group(backend)
     return world()
 
 

@@ -1,6 +1,7 @@
 """The two trainers end to end on the MI355X HIP path (default backend), synthetic data + stub OCR."""
 import json
 import os
+import sys
 
 import pytest
 import torch
@@ -229,3 +230,48 @@ def test_eager_forward_after_graph_replays_sees_the_new_weights():
         ops.WEIGHT_CACHE["on"] = True
     assert not torch.equal(before, fresh)                     # the replays did move the weights
     assert torch.equal(cached, fresh)
+
+
+def _dp_gpu_worker(rank, world, port, tmp):
+    """two ranks SHARING cuda:0 (gloo moves the flat gradient buffers through the host): the product's HIP backend end to end under
+    the data-parallel path — equal shards, whole-minibatch TopKCER over the ranks, winner re-balance, two all-reduces per step"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      QEA_DIST_BACKEND="gloo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "query-efficient-approx-to-improve-ocr_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from datasets.synthetic import SyntheticTextAreas
+    from qea import dist as qdist
+    from train_nn_area import TrainNNPrep
+    tr = SyntheticTextAreas(16, seed=3, include_name=True, include_index=True)
+    cers_path = os.path.join(tmp, f"cers{rank}.json")
+    json.dump({n: ((i * 7) % 16) / 16 for i, n in enumerate(tr.names)}, open(cers_path, "w"))
+    args = _args("a", os.path.join(tmp, f"exp{rank}"), batch_size=4, minibatch_subset="topKCER", minibatch_subset_prop=0.5,
+                 cers_ocr_path=cers_path, inner_limit=2)
+    t = TrainNNPrep(args, train_set=tr, val_set=SyntheticTextAreas(4, seed=4, include_name=True))
+    assert t.world == world and t.device.type == "cuda"
+    seen = []
+    rb = qdist.rebalance_rows
+    qdist.rebalance_rows = lambda rows, counts: (seen.append((rows.shape[0], list(counts))), rb(rows, counts))[1]
+    t.train()
+    flat = torch.cat([p.detach().flatten() for p in t.prep_model.parameters()] + [p.detach().flatten() for p in t.crnn_model.parameters()]).cpu()
+    picked = sorted(n for n, v in t.selected_samples.items() if v[0])
+    torch.save({"flat": flat, "picked": picked, "rebalanced": seen, "steps": len(t.loader_train)}, os.path.join(tmp, f"dp_r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_on_one_gpu(tmp_path):
+    """SURVEY §8e on hardware, as far as one card allows: 2 ranks x batch 4 on the HIP backend (gloo in place of RCCL, which refuses two
+    ranks on one device): both ranks run the same number of steps, hold bit-identical weights after every pair of all-reduces, the
+    union of their picks is the global top-k of each minibatch and the winners were dealt out in equal slices."""
+    import torch.multiprocessing as mp
+    port = 32500 + os.getpid() % 2000
+    mp.start_processes(_dp_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "dp_r0.pt"), torch.load(tmp_path / "dp_r1.pt")
+    assert r0["steps"] == r1["steps"] == 2                                        # 16 samples / (2 ranks x 4)
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.isfinite(r0["flat"]).all()
+    assert len(r0["picked"]) + len(r1["picked"]) == 2 * 4 and not set(r0["picked"]) & set(r1["picked"])   # k = 4 of each global batch of 8
+    for a, b in zip(r0["rebalanced"], r1["rebalanced"]):
+        assert a[1] == b[1] and sum(a[1]) == 4 and a[0] == a[1][0] and b[0] == b[1][1]                     # the same plan on both ranks
