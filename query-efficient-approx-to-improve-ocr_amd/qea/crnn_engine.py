@@ -182,7 +182,9 @@ class CRNNEngine:
         g = dlp.contiguous().view(TB, V)
         dlogits = torch.empty(TB, vp, device=dev)
         ops.log_softmax_bwd(g, V, ctx["lp"], vp, dlogits, vp, TB, V, vp, nan_scrub)
-        f16 = ops.amax_pool(dev) is not None                      # the split-fp16 GEMMs below want their operands' abs-max
+        pool_ = ops.amax_pool(dev)                                # abs-max slots of this pass (None: the fp16 split is off)
+        slot = (lambda: pool_.slot()) if pool_ is not None else (lambda: None)
+        f16 = pool_ is not None                                   # the split-fp16 GEMMs below want their operands' abs-max
         dl_amax = ops.absmax(dlogits, vp, TB, vp) if f16 else None
 
         # Linear
@@ -255,7 +257,7 @@ class CRNNEngine:
             else:
                 # rows (t,b) -> output row b*T + t : the gradient of conv7's output in its own [B,1,T,512] order
                 dseq_bt = torch.empty(B, T, 512, device=dev)
-                dseq_amax = ops.amax_pool(dev).slot() if f16 else None
+                dseq_amax = slot()
                 ops.conv_igemm(gates, wT, dseq_bt, B=T, H=1, W=B, Cin=8 * HID, OH=1, OW=B, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512,
                                out_mode=ops.OUT_TBC, x_amax=g_amax, y_amax=dseq_amax, w_src=("catT", wf))
 
@@ -278,8 +280,6 @@ class CRNNEngine:
         ops.maxpool_bwd(acts["a6"], 512, dp6, 512, da, 512, B, h, w, 512, 2, 1, relu_mask=False)
         bn_training = ctx["bn_training"]
         amx = ctx.get("amx", {})                                  # forward tensors' abs-max (a replica-group slice keeps its tensor's bound)
-        pool_ = ops.amax_pool(dev)
-        slot = (lambda: pool_.slot()) if pool_ is not None else (lambda: None)
         for name, bn, cin, src in (("conv6", "batchnorm2", 512, "a5"), ("conv5", "batchnorm1", 256, "p4")):
             M = B * h * w
             k = name[-1]
