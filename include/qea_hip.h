@@ -33,7 +33,7 @@ extern "C" {
 #define QEA_ERR_LAUNCH (-2)
 #define QEA_ERR_WORKSPACE (-3)
 
-/* ABI version; bumped whenever a struct below changes. */
+/* ABI version; bumped whenever a struct below changes or entry points are added. */
 int qea_version(void);
 const char* qea_last_error(void);
 
@@ -146,7 +146,15 @@ int qea_conv_igemm(const qea_conv_desc* d, void* stream);
 /* 1 when qea_conv_igemm would run this launch on a split-bf16 tile (so that pre-split operands pay), else 0 */
 int qea_conv_igemm_uses_split_bf16(const qea_conv_desc* d);
 int qea_conv_igemm_stats_blocks(const qea_conv_desc* d);
+/* 1: the launch would run on the LDS-halo 3x3 kernel (tile 24) given w_frag_planes = qea_pack_frag_planes / _f16 of the filter;
+ * 2 (ABI v7): it would run on the 1x1 LDS tile (tile 26) given x_absmax and w_frag_planes = qea_pack_frag_planes_f16_1x1; 0: neither */
 int qea_conv_igemm_wants_frag_planes(const qea_conv_desc* d);
+/* ABI v7 (additive).  Filter [N][K] of a 1x1 stride-1 GEMM (N % 128 == 0, K % 64 == 0) as two fp16 planes in the fragment order of
+ * tile 26, scaled from wmax[0] like qea_pack_frag_planes_f16, followed by one float = the inverse scale.  Tile 26 replaces the
+ * generic split tiles for the launches behind nn.ConvTranspose2d forward (/root/reference/models/model_unet.py:25-44, 61-73), the BiLSTM
+ * input projections and their input gradients (/root/reference/models/model_crnn.py:9) when the two-way fp16 split is on. */
+size_t qea_pack_frag_planes_f16_1x1_bytes(int32_t N, int32_t K);
+int qea_pack_frag_planes_f16_1x1(const float* w, int32_t N, int32_t K, const float* wmax, void* planes, void* stream);
 /* ABI v6.  out[0] = max |x[r*ld + c]| over r < M, c < C with NaN / inf elements ignored (a non-finite element must not decide the
  * scale of the finite ones: it stays non-finite in the products it enters).  One pass over the tensor; `out` is overwritten. */
 int qea_absmax(const float* x, int32_t ld, int64_t M, int32_t C, float* out, void* stream);

@@ -11,7 +11,7 @@ mkdir -p obj
 pids=()
 for f in *.hip; do
   o=obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ ! -f "${o%.o}.res" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/qea_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ ! -f "${o%.o}.res" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o")" ] || [ ../../include/qea_hip.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Rpass-analysis=kernel-resource-usage $QEA_EXTRA_HIPCC_FLAGS \
       -c "$f" -o "$o" 2> "${o%.o}.res.tmp" && mv "${o%.o}.res.tmp" "${o%.o}.res" &
     pids+=($!)

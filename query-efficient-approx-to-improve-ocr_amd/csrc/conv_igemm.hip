@@ -10,121 +10,15 @@
 // lane (r = l&31, h = l>>5), MFMA step s  ->  k = 4h + s  on both operands.
 //
 // Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); 2*M*N*K algorithmic flops/launch.
-#include "common.h"
+#include "conv_args.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
+using qea_conv::ConvArgs;
+using qea_conv::conv_epilogue;
+
 namespace {
-
-struct ConvArgs {
-  const float* x;
-  const float* w;
-  float* y;
-  const float* scale;
-  const float* bias;
-  const float* mask;
-  int B, H, W, Cin, OH, OW, N, KH, KW, pad_h, pad_w, stride_h, stride_w;
-  int ldx, ldy, ldmask, relu, accumulate, out_mode;
-  int M, K, n_tiles, m_tiles;
-  // pre-split operands (P3 format, see qea_split_planes): byte pointers + the byte offset of each buffer's zero chunk
-  const char* xp;
-  const char* wp;
-  unsigned xp_zero, wp_zero;
-  // fused BatchNorm batch statistics (STATS kernels): per (M-tile, wave row) partial column sums [blocks][N][2] in fp64
-  double* stats;
-  // two-way fp16 split (QEA_MFMA_SPLIT_F16): largest finite |x| of the input tensor (device scalar) — the filter's is in its planes
-  const float* xmax;
-  // producer-carried abs-max of the stored outputs (qea_conv_desc.y_absmax), or null
-  float* yamax;
-};
-
-// Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,
-// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Order: v = acc*scale + bias; relu; mask; accumulate; store (out_mode remaps).
-// STATS: additionally accumulate, per output column, sum and sum of squares of the STORED values in fp64 (rows past M hold
-// zero accumulators and add nothing) and write one partial per (M-tile, wave row): the batch statistics of the BatchNorm
-// that follows (models/model_unet.py:78-109) without a second pass over the conv output.
-template <int MI, int NJ, int TM, int TN, bool STATS = false>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&acc)[MI][NJ], int m0, int n0, int wm, int wn, int fr, int fh,
-                                              int stats_block = 0) {
-  const int ohw = p.OH * p.OW;
-  float am = 0.f;
-  double st0[NJ], st1[NJ];
-  if (STATS) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) st0[j] = st1[j] = 0.0;
-  }
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      if (m >= p.M) continue;
-      size_t orow;  // output row (pixel) index for QEA_OUT_NHWC / TBC
-      int cb = 0, ch = 0, cw = 0;
-      if (p.out_mode == QEA_OUT_NHWC) {
-        orow = (size_t)m;
-      } else if (p.out_mode == QEA_OUT_TBC) {
-        const int b = m / p.OW;
-        const int ow = m - b * p.OW;
-        orow = (size_t)ow * p.B + b;
-      } else {
-        cb = m / ohw;
-        const int rem = m - cb * ohw;
-        ch = rem / p.OW;
-        cw = rem - ch * p.OW;
-        orow = 0;
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * TN + j * 32 + fr;
-        if (n >= p.N) continue;
-        float v = acc[i][j][r];
-        size_t o;
-        int nb = n;
-        if (p.out_mode == QEA_OUT_CONVT) {
-          const int co_n = p.N >> 2;
-          const int ab = n / co_n;
-          nb = n - ab * co_n;
-          const size_t opix = ((size_t)cb * (2 * p.OH) + 2 * ch + (ab >> 1)) * (2 * p.OW) + 2 * cw + (ab & 1);
-          o = opix * p.ldy + nb;
-        } else {
-          o = orow * p.ldy + n;
-        }
-        if (p.scale && p.bias) v = __fmaf_rn(v, p.scale[n], p.bias[nb]);  // the very fma qea_bn_apply evaluates
-        else if (p.scale) v *= p.scale[n];
-        else if (p.bias) v += p.bias[nb];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.mask) {
-          const size_t mo = (p.out_mode == QEA_OUT_CONVT) ? (o / p.ldy) * p.ldmask + nb : orow * p.ldmask + n;
-          v = (p.mask[mo] > 0.f) ? v : 0.f;
-        }
-        if (p.accumulate) v += p.y[o];
-        p.y[o] = v;
-        am = qea_amax_acc(am, v);
-        if (STATS) {
-          st0[j] += (double)v;
-          st1[j] += (double)v * (double)v;
-        }
-      }
-    }
-  }
-  qea_amax_commit(am, p.yamax);                            // (every lane of the workgroup runs the epilogue to its end)
-  if (STATS) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      // the two lane halves hold different rows of the same column
-      const double a = st0[j] + __shfl_xor(st0[j], 32, 64);
-      const double b = st1[j] + __shfl_xor(st1[j], 32, 64);
-      const int n = n0 + wn * TN + j * 32 + fr;
-      if (fh == 0 && n < p.N) {
-        double* dst = p.stats + ((size_t)stats_block * p.N + n) * 2;
-        dst[0] = a;
-        dst[1] = b;
-      }
-    }
-  }
-}
 
 // Per-thread operand fetch shared by the fp32 and the split-bf16 kernel: thread (lrow, kc) gathers float4 number kc of
 // the K slice for A_LD rows of the im2col matrix (zero outside the image / past M) and B_LD rows of the filter.
@@ -1081,8 +975,15 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
 // NPL = 3: three bf16 planes, six MFMAs per product.  NPL = 2 (round 3, QEA_MFMA_SPLIT_F16): two fp16 planes of the SCALED
 // operands (qea_split2_f16; scales from the input's abs-max `xmax` and from the tail of the filter planes), three MFMAs per
 // product, two thirds of the LDS; the accumulators are un-scaled in the epilogue (exact: powers of two).
+#ifndef QEA_HALO_NARROW_WGS
+#define QEA_HALO_NARROW_WGS 3
+#endif
+// workgroups per CU: two where the LDS allows no more; three for the narrow fp16 instances (<= 52 KB of LDS each), whose tiles are
+// bound by the latency of their halo gather and stores, not by the MFMA pipe
+constexpr int halo_bf3_wgs(int cin, int cout, int npl) { return (npl == 2 && cout <= 64 && (cin == 32 || cout == 32) && QEA_HALO_NARROW_WGS == 3) ? 3 : 2; }
+
 template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wgs(CIN, COUT, NPL), halo_bf3_wgs(CIN, COUT, NPL)))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
                                                                int Ntot, const float* __restrict__ mask, int ldmask, int total,
@@ -1440,10 +1341,11 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return 2 * (cus & ~7);
+    return halo_bf3_wgs(CIN, COUT, NPL) * (cus & ~7);
   }();
   // (32-channel outputs keep one item per workgroup: two persistent workgroups of a CU fall into lockstep there — both staging,
   // then both in their MFMA phase — and lose the overlap that staggered dispatch gives: 150-159 vs 159-166 TFLOP/s measured)
+  // (re-measured with the fp16 split and three workgroups per CU: persistent 0.779 / 1.431 ms against 0.750 / 1.331 one item each)
   const unsigned grid = (total > resident && COUT > 32) ? (unsigned)resident : (unsigned)total;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
                      a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total, a.xmax, a.yamax);
@@ -1517,6 +1419,14 @@ int launch_halo_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
 // 32->32 168 vs 95 fp32-halo; 128->64 211 vs 140; 128->128 208 vs 186; 256->256 226 vs 215; 512->512 238 vs 226 TFLOP/s).
 bool halo_bf3_wins(const qea_conv_desc* d) { return halo_bf3_eligible(d); }
 
+// tile 26 (gemm1x1.hip): 1x1 stride-1 GEMMs on the 128-row LDS tile, two-way fp16 split only (needs x_absmax + the planes of
+// qea_pack_frag_planes_f16_1x1): K a multiple of 64, N a multiple of 128, bias / ReLU epilogue, NHWC / TBC / transposed-conv store
+bool gemm1x1_eligible(const qea_conv_desc* d) {
+  return d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OH == d->H && d->OW == d->W &&
+         d->Cin % 64 == 0 && d->N % 128 == 0 && !d->scale && !d->mask && !d->accumulate && !d->stats &&
+         (long long)d->N * d->Cin * 4 < 0x7fffffffLL;
+}
+
 // Tile choice for tile == 0 (measured on MI355X with tools/bench_conv.py)
 int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
   int tile = 0;
@@ -1535,7 +1445,8 @@ int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
   const bool bf3 = qea_split_bf16_enabled() && d->N >= 128 && a.K >= 256;
   // 33..64 output channels: the split-bf16 256x64 tile beats both the fp32 256x64 tile (132 vs 107 TFLOP/s at Cin = 128) and
   // the fp32 LDS-halo kernel at Cin = 64 (120 vs 111); the halo kernel keeps Cin = 32 (K = 288: 102 vs 91)
-  if (qea_split_bf16_enabled() && d->tile != -1 && halo_bf3_wins(d)) tile = 24;   // narrow layers: split-bf16 LDS-halo kernel (168-208 vs 95-120 TFLOP/s)
+  if (qea_split_bf16_enabled() && d->tile != -1 && gemm1x1_eligible(d)) tile = 26;     // 1x1 / transposed-conv GEMMs: 128-row LDS tile (fp16 split)
+  else if (qea_split_bf16_enabled() && d->tile != -1 && halo_bf3_wins(d)) tile = 24;   // narrow layers: split-bf16 LDS-halo kernel (168-208 vs 95-120 TFLOP/s)
   else if (qea_split_bf16_enabled() && d->N > 32 && d->N <= 64 && a.K >= 256 && d->Cin >= 64) tile = 23;
   else if (halo_eligible(d)) tile = 4;
   // transposed convolutions (forward scatter / stride-2 input gradient) with K <= 256: traffic-bound launches of 4-16 K
@@ -1561,9 +1472,9 @@ int pick_tile(const qea_conv_desc* d, const ConvArgs& a) {
 // narrow-layer split kernel was chosen but the caller did not supply the fragment-order filter planes
 int resolve_tile(const qea_conv_desc* d, const ConvArgs& a) {
   int tile = d->tile ? d->tile : pick_tile(d, a);
-  if (tile == 24 && !d->tile && !d->w_frag_planes) {
+  if (!d->tile && ((tile == 24 && !d->w_frag_planes) || (tile == 26 && !(d->w_frag_planes && d->x_absmax)))) {
     qea_conv_desc e = *d;
-    e.tile = -1;                                           // the choice without tile 24
+    e.tile = -1;                                           // the choice without tiles 24 / 26
     tile = pick_tile(&e, a);
   }
   return tile;
@@ -1660,10 +1571,19 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     qea_set_error("qea_conv_igemm: tile 24 needs Cin = 32 or 64k <= 512, N in {32,64,128k}, 3x3 pad 1 stride 1, W %% 32 == 0 (or 4x16 / 2x8 images with Cin = 64k, N = 128k), no accumulate, and w_frag_planes");
     return QEA_ERR_INVALID;
   }
+  if (tile == 26 && (!gemm1x1_eligible(d) || !d->w_frag_planes || !d->x_absmax)) {
+    qea_set_error("qea_conv_igemm: tile 26 needs a 1x1 stride-1 GEMM with Cin %% 64 == 0, N %% 128 == 0, no scale / mask / accumulate / stats, x_absmax and the w_frag_planes of qea_pack_frag_planes_f16_1x1");
+    return QEA_ERR_INVALID;
+  }
   qea_prof_begin(QEA_PROF_CONV_IGEMM, s);
   int rc;
   switch (tile) {
     case 4: rc = launch_halo_any(d, a, s); break;
+    case 26:                                               // 1x1 / transposed-conv GEMM on the 128-row LDS tile (gemm1x1.hip)
+      a.wp = (const char*)d->w_frag_planes;
+      a.xmax = d->x_absmax;
+      rc = qea_conv::launch_gemm1x1_f16(a, s);
+      break;
     case 24:                                               // split-bf16 LDS-halo kernel of the narrow layers: filter in fragment-order planes
       a.wp = (const char*)d->w_frag_planes;
       a.xmax = d->x_absmax;                                // non-NULL: fp16 planes + scales (ABI v6)
@@ -1762,7 +1682,9 @@ extern "C" int qea_pack_frag_planes_f16(const float* w, int32_t N, int32_t Cin, 
   return QEA_OK;
 }
 
-/* 2 when qea_conv_igemm would pick the narrow-layer split-bf16 LDS-halo kernel (tile 24: wants w_frag_planes), else 0 */
+/* 1 when qea_conv_igemm would pick the LDS-halo kernel (tile 24: wants the w_frag_planes of qea_pack_frag_planes[_f16]); 2 when it
+ * would pick the 1x1 LDS tile (tile 26: wants those of qea_pack_frag_planes_f16_1x1 AND x_absmax — without them the launch runs on
+ * the generic tiles); else 0 */
 extern "C" int qea_conv_igemm_wants_frag_planes(const qea_conv_desc* d) {
   if (!d || d->Cin <= 0 || d->Cin % 32 || d->B <= 0) return 0;
   ConvArgs a;
@@ -1771,5 +1693,5 @@ extern "C" int qea_conv_igemm_wants_frag_planes(const qea_conv_desc* d) {
   a.N = d->N;
   a.K = d->KH * d->KW * d->Cin;
   const int tile = d->tile ? d->tile : pick_tile(d, a);
-  return tile == 24 ? 1 : 0;
+  return tile == 24 ? 1 : (tile == 26 ? 2 : 0);
 }

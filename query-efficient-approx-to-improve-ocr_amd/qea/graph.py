@@ -20,9 +20,14 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from . import ops
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fn()
+        ops.CAPTURE["token"] = object()                  # derived weight forms: built once per weight epoch inside the graph
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = fn()
+        finally:
+            ops.CAPTURE["token"] = None
 
     def __call__(self):
         self.graph.replay()

@@ -57,14 +57,15 @@ PRESPLIT = {"on": True, "x": False}     # tests / tools: "on" = pre-split filter
 # ---- derived forms of WEIGHTS (dgrad filter layouts, transposes, P3 planes), kept until the weights change.
 # A weight tensor changes either through torch (load_state_dict, copy_: its _version moves) or through the fused Adam kernel
 # (raw pointer writes: qea.optim.FusedAdam.step calls bump_weight_epoch()).  With the CRNN frozen in Phase B its derived forms
-# are built once, not once per step (round 1 re-derived 390 filter layouts per step).  Nothing is cached while a hipGraph is
-# being captured: a replay must re-derive from the weights it finds.
+# are built once, not once per step (round 1 re-derived 390 filter layouts per step).  Inside a hipGraph capture the cache is
+# scoped to that capture (see weight_cached): a replay re-derives every form from the weights it finds, once per weight epoch.
 # RULE for any other writer: a write that goes through `p.data` (torch.distributed.broadcast(p.data), p.data.copy_, an EMA) or
 # through a raw pointer moves neither _version nor the epoch — call bump_weight_epoch() after it (qea.graph.GraphedStep does
 # after every replay, TrainerCore after the start-up broadcast, qea.params.FlatState when it re-homes the parameters).
 _wcache = {}
 _wepoch = [0]
 WEIGHT_CACHE = {"on": True}
+CAPTURE = {"token": None}
 
 
 def bump_weight_epoch():
@@ -75,10 +76,18 @@ def weight_cached(kind, w, build, also=()):
     """build() -> tensor(s) derived from the weight tensor `w` (and the tensors in `also`) only; cached per (kind, the
     tensor OBJECT) until one of them changes.  Entries die with the tensor object (weakref), so a new tensor that happens
     to reuse the address of a freed one can never hit."""
-    if not WEIGHT_CACHE["on"] or torch.cuda.is_current_stream_capturing():
+    token = None
+    if torch.cuda.is_current_stream_capturing():
+        # inside a capture made by qea.graph.GraphedStep a derived form is built once per weight epoch OF THAT CAPTURE (the build
+        # launches are part of the graph and run before their uses on every replay); an entry carries the capture's token, so
+        # neither eager code nor another capture can ever hit it.  Any other capture caches nothing.
+        token = CAPTURE["token"]
+        if token is None:
+            return build()
+    if not WEIGHT_CACHE["on"]:
         return build()
     key = (kind, id(w))
-    ver = (w.data_ptr(), w._version, _wepoch[0], _stream()) + tuple((id(t), t.data_ptr(), t._version) for t in also)
+    ver = (w.data_ptr(), w._version, _wepoch[0], _stream(), token) + tuple((id(t), t.data_ptr(), t._version) for t in also)
     hit = _wcache.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is w:
         return hit[1]
@@ -121,14 +130,26 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
                       relu=int(relu), accumulate=int(accumulate), out_mode=out_mode, tile=tile, x_planes=None, w_planes=None, stats=None,
                       w_frag_planes=None)
     frag = xmax = None
-    if PRESPLIT["on"] and L.qea_conv_igemm_wants_frag_planes(C.byref(d)):
+    wants = L.qea_conv_igemm_wants_frag_planes(C.byref(d)) if PRESPLIT["on"] else 0
+    if wants == 2 and SPLIT_F16["on"] and x_planes is None and w_planes is None:
+        # 1x1 GEMM on the 128-row LDS tile (tile 26, fp16 split only): filter [N][K] in fragment-order fp16 planes (cached)
+        def build():
+            out = torch.empty(L.qea_pack_frag_planes_f16_1x1_bytes(N, Cin), dtype=torch.uint8, device=x.device)
+            wmax = filter_absmax(w_src, w, Cin, N, Cin)
+            _lib.check(L.qea_pack_frag_planes_f16_1x1(_ptr(w), N, Cin, _ptr(wmax), out.data_ptr(), _stream()), "qea_pack_frag_planes_f16_1x1")
+            return out
+        frag = weight_cached(("frag1x1", w_src[0], N, Cin), w_src[1], build) if w_src is not None else build()
+        d.w_frag_planes = frag.data_ptr()
+        xmax = x_amax if x_amax is not None else absmax(x, ldx, B * H * W, Cin)
+        d.x_absmax = xmax.data_ptr()
+    elif wants == 1:
         # 3x3 layer on the split LDS-halo kernel: its filter in fragment-order planes (a few hundred KB, cached)
         f16 = SPLIT_F16["on"]
 
         def build():
             if f16:
                 out = torch.empty(L.qea_pack_frag_planes_f16_bytes(N, Cin), dtype=torch.uint8, device=x.device)
-                wmax = absmax(w, 9 * Cin, N, 9 * Cin)
+                wmax = filter_absmax(w_src, w, 9 * Cin, N, 9 * Cin)
                 _lib.check(L.qea_pack_frag_planes_f16(_ptr(w), N, Cin, _ptr(wmax), out.data_ptr(), _stream()), "qea_pack_frag_planes_f16")
                 return out
             out = torch.empty(L.qea_pack_frag_planes_bytes(N, Cin), dtype=torch.uint8, device=x.device)
@@ -149,7 +170,7 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
                 x_planes = split_planes(x, ldx, B * H * W, Cin)
             f16 = SPLIT_F16["on"] and x_planes is None and w_planes is None and N * K * 4 < (1 << 31) - 256
             if w_planes is None:
-                build = (lambda: split_planes_f16(w, K, N, K)) if f16 else (lambda: split_planes(w, K, N, K))
+                build = (lambda: split_planes_f16(w, K, N, K, w_src)) if f16 else (lambda: split_planes(w, K, N, K))
                 w_planes = weight_cached(("planesf16" if f16 else "planes", w_src[0], N, K), w_src[1], build) if w_src is not None else build()
             d.x_planes = x_planes.data_ptr() if x_planes is not None else None
             d.w_planes = w_planes.data_ptr()
@@ -237,11 +258,23 @@ def amax_pool(device):
     return AmaxPool(device) if (SPLIT_F16["on"] and mfma_mode() == "split_f16") else None
 
 
-def split_planes_f16(x, ld, M, Cc):
+def filter_absmax(w_src, w, ld, M, Cc):
+    """The abs-max a filter's fp16 planes are scaled from.  A filter that lives in a model's flat parameter buffer (qea.params)
+    takes the abs-max of the WHOLE buffer, computed once per weight update for all its filters (one launch instead of one per
+    filter and derived form): any bound >= the filter's own max is a valid scale source, and the fp16 pair keeps all 22 bits of
+    every element down to 2^-17 of the bound, far below the spread between a model's layers."""
+    from .params import flat_state_of
+    fs = flat_state_of(w_src[1]) if w_src is not None else None
+    if fs is None or fs.total % 4:
+        return absmax(w, ld, M, Cc)
+    return weight_cached("flat_absmax", fs.data, lambda: absmax(fs.data, fs.total, 1, fs.total))
+
+
+def split_planes_f16(x, ld, M, Cc, w_src=None):
     """the two-plane fp16 row format of a FILTER (qea_split_planes_f16), scaled by the power of two of its abs-max"""
     L = _lib.lib()
     out = torch.empty(L.qea_split_planes_f16_bytes(M, Cc), dtype=torch.uint8, device=x.device)
-    xmax = absmax(x, ld, M, Cc)
+    xmax = filter_absmax(w_src, x, ld, M, Cc)
     _lib.check(L.qea_split_planes_f16(_ptr(x), ld, M, Cc, _ptr(xmax), out.data_ptr(), _stream()), "qea_split_planes_f16")
     return out
 

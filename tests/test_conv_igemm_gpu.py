@@ -305,3 +305,61 @@ def test_narrow_split_bf16_halo_kernel(Cin, Cout, H, W, B):
                    ldmask=Cout + 32)
     want3 = ref.permute(0, 2, 3, 1) * (mk[..., 32:].cpu() > 0)
     assert (y3.cpu().double() - want3).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,K,N,mode", [(1000, 64, 128, "nhwc"), (128 * 5, 512, 1024, "nhwc"), (777, 2048, 512, "tbc"), (4 * 6 * 10, 128, 256, "convt"),
+                                       (3 * 2 * 8, 512, 1024, "convt"), (16 * 16 * 64, 64, 128, "convt"), (130, 192, 384, "nhwc")])
+def test_gemm1x1_lds_tile(M, K, N, mode):
+    """tile 26 (gemm1x1.hip): 1x1 GEMM / transposed-conv forward on the 128-row LDS tile, two-way fp16 split, against fp64 — plain rows,
+    the (t,b) -> (b,t) row transpose (QEA_OUT_TBC) and the 2x2 stride-2 scatter into one half of a concat buffer (QEA_OUT_CONVT,
+    /root/reference/models/model_unet.py:61-73), rows past M in the last tile, bias + ReLU, strided input rows"""
+    from qea import _lib, ops
+    prev = ops.set_mfma_mode("split_f16")
+    try:
+        g = torch.Generator().manual_seed(M + K)
+        ldx = K + 64
+        xfull = torch.randn(M, ldx, generator=g)
+        x = xfull[:, :K]
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        relu = mode == "nhwc"
+        xd, wd = xfull.cuda(), w.cuda()
+        amax = torch.zeros(1, device="cuda")
+        if mode == "convt":
+            c = N // 4
+            bias = torch.randn(c, generator=g)
+            B, h, wd_ = {4 * 6 * 10: (4, 6, 10), 3 * 2 * 8: (3, 2, 8), 16 * 16 * 64: (16, 16, 64)}[M]
+            ref = (x.double() @ w.double().t()).view(B, h, wd_, 2, 2, c) + bias.double()
+            ref = ref.permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * wd_, c)
+            y = torch.full((B, 2 * h, 2 * wd_, 2 * c), float("nan"), device="cuda")
+            d = dict(B=B, H=h, W=wd_, OH=h, OW=wd_, ldy=2 * c, out_mode=ops.OUT_CONVT)
+            pick = lambda t: t[..., :c]
+        else:
+            bias = torch.randn(N, generator=g)
+            ref = x.double() @ w.double().t() + bias.double()
+            if relu:
+                ref = ref.relu()
+            y = torch.full((M, N + 32), float("nan"), device="cuda")
+            d = dict(B=1, H=1, W=M, OH=1, OW=M, ldy=N + 32, out_mode=ops.OUT_NHWC)
+            pick = lambda t: t[:, :N]
+            if mode == "tbc":                                   # M = T * Bt rows (t, b) -> output row b * T + t
+                T, Bt = 7, M // 7
+                ref = ref.view(T, Bt, N).permute(1, 0, 2).reshape(M, N)
+                d = dict(B=T, H=1, W=Bt, OH=1, OW=Bt, ldy=N + 32, out_mode=ops.OUT_TBC)
+        desc = _lib.ConvDesc(x=None, w=None, y=None, scale=None, bias=None, mask=None, B=d["B"], H=d["H"], W=d["W"], Cin=K, OH=d["OH"], OW=d["OW"], N=N,
+                             KH=1, KW=1, pad_h=0, pad_w=0, stride_h=1, stride_w=1, ldx=ldx, ldy=d["ldy"], ldmask=0, relu=int(relu), accumulate=0,
+                             out_mode=d["out_mode"], tile=0, x_planes=None, w_planes=None, stats=None, w_frag_planes=None)
+        assert _lib.lib().qea_conv_igemm_wants_frag_planes(C.byref(desc)) == 2          # the automatic choice is tile 26
+        ops.prof_enable(ops.PROF_CONV_IGEMM, True)
+        ops.prof_reset()
+        ops.conv_igemm(xd, wd, y, Cin=K, N=N, KH=1, KW=1, ldx=ldx, bias=bias.cuda(), relu=relu, y_amax=amax, **d)
+        torch.cuda.synchronize()
+        assert ops.prof_read_tagged(ops.PROF_CONV_IGEMM, 26)["launches"] == 1
+        ops.prof_enable(ops.PROF_CONV_IGEMM, False)
+        got = pick(y).cpu().double()
+        assert torch.isnan(y[..., (N // 4 if mode == "convt" else N):]).all()           # nothing written outside the output columns
+        scale = ref.abs().max().item()
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-6 * max(scale, 1.0), (err, scale)                                 # fp32-class: the split drops < 2^-22 per product
+        assert abs(amax.item() - got.abs().max().item()) <= 1e-6 * scale
+    finally:
+        ops.set_mfma_mode(prev)

@@ -14,7 +14,10 @@ from bench_convt import timeit  # noqa: E402
 def main():
     TB = int(sys.argv[1]) if len(sys.argv) > 1 else 63488
     tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 20, 21, 22, 25]
-    for (N, K) in ((1024, 512), (512, 2048), (96, 512), (512, 96)):
+    shapes = ((1024, 512), (512, 2048), (96, 512), (512, 96))
+    if os.environ.get("GEMM_SHAPES"):                     # e.g. GEMM_SHAPES=1024x512,512x2048
+        shapes = tuple(tuple(int(v) for v in sh.split("x")) for sh in os.environ["GEMM_SHAPES"].split(","))
+    for (N, K) in shapes:
         x = torch.randn(TB, K, device="cuda")
         w = torch.randn(N, K, device="cuda")
         y = torch.empty(TB, N, device="cuda")
