@@ -1424,7 +1424,8 @@ bool halo_bf3_wins(const qea_conv_desc* d) { return halo_bf3_eligible(d); }
 bool gemm1x1_eligible(const qea_conv_desc* d) {
   return d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OH == d->H && d->OW == d->W &&
          d->Cin % 64 == 0 && d->N % 128 == 0 && !d->scale && !d->mask && !d->accumulate && !d->stats &&
-         (long long)d->N * d->Cin * 4 < 0x7fffffffLL;
+         (long long)d->N * d->Cin * 4 < 0x7fffffffLL &&
+         (d->out_mode != QEA_OUT_CONVT || (long long)d->B * d->H * d->W * 4 < 0x7fffffffLL);   // (output pixel rows are kept as int32)
 }
 
 // Tile choice for tile == 0 (measured on MI355X with tools/bench_conv.py)
