@@ -363,3 +363,46 @@ def test_gemm1x1_lds_tile(M, K, N, mode):
         assert abs(amax.item() - got.abs().max().item()) <= 1e-6 * scale
     finally:
         ops.set_mfma_mode(prev)
+
+
+@pytest.mark.parametrize("ratio", [1.0, 2.0 ** 10, 2.0 ** 16])
+def test_filter_scale_from_the_whole_parameter_buffer(ratio):
+    """The fp16 planes of every filter of a model are scaled from ONE number, the abs-max of the model's flat parameter buffer
+    (ops.filter_absmax).  A filter whose own maximum is `ratio` times smaller than that bound must keep fp32-class accuracy: the
+    h + l pair carries 22 bits down to 2^-17 of the bound.  3x3 layer (tile 24) and 1x1 GEMM (tile 26), against fp64."""
+    from qea import ops
+    from qea.params import FlatState, flat_state_of
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(5)
+            self.w3 = torch.nn.Parameter((torch.randn(128, 64, 3, 3, generator=g) / 24.0).to(memory_format=torch.channels_last))
+            self.w1 = torch.nn.Parameter(torch.randn(256, 128, generator=g) / 11.0)
+            self.big = torch.nn.Parameter(torch.full((4,), 1.0))
+
+    prev = ops.set_mfma_mode("split_f16")
+    try:
+        m = M().cuda()
+        with torch.no_grad():
+            m.big.fill_(float(m.w3.abs().max()) * ratio)
+        fs = FlatState(m)
+        ops.bump_weight_epoch()
+        assert flat_state_of(m.w3) is fs
+        bound = ops.filter_absmax(("fwd", m.w3), m.w3, 9 * 64, 128, 9 * 64)
+        assert abs(bound.item() - fs.data.abs().max().item()) == 0.0                  # the bound is the buffer's abs-max, not the filter's
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(3, 8, 32, 64, generator=g)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), m.w3.detach().cpu().double(), padding=1).permute(0, 2, 3, 1)
+        y = torch.empty(3, 8, 32, 128, device="cuda")
+        ops.conv_igemm(x.cuda(), m.w3, y, B=3, H=8, W=32, Cin=64, OH=8, OW=32, N=128, KH=3, KW=3, pad=(1, 1), ldx=64, ldy=128, w_src=("fwd", m.w3))
+        err = (y.cpu().double() - ref).abs().max().item()
+        assert err <= 2e-6 * ref.abs().max().item(), (ratio, err, ref.abs().max().item())
+        x1 = torch.randn(500, 128, generator=g)
+        ref1 = x1.double() @ m.w1.detach().cpu().double().t()
+        y1 = torch.empty(500, 256, device="cuda")
+        ops.conv_igemm(x1.cuda(), m.w1, y1, B=1, H=1, W=500, Cin=128, OH=1, OW=500, N=256, KH=1, KW=1, ldx=128, ldy=256, w_src=("fwd", m.w1))
+        err1 = (y1.cpu().double() - ref1).abs().max().item()
+        assert err1 <= 2e-6 * ref1.abs().max().item(), (ratio, err1)
+    finally:
+        ops.set_mfma_mode(prev)
