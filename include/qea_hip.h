@@ -266,6 +266,12 @@ int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, float* out, in
  * a ReLU output); accumulate: dx += (UNet skip connections). */
 int qea_maxpool_fwd(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C,
                     int32_t kh, int32_t kw, float* absmax_out, void* stream);
+/* ABI v7 (additive).  qea_bn_apply followed by qea_maxpool_fwd in ONE pass over y [B,H,W,C]: a = relu?(y*scale + shift) at full
+ * resolution (pixel stride lda) and pooled = max-pool(a) (pixel stride ldp), both bit-identical to the two separate calls, which
+ * read the activation a second time (model_unet.py:51-59: encoder block -> MaxPool2d(2,2)); absmax_a / absmax_pooled as absmax_out. */
+int qea_bn_apply_pool(const float* y, int32_t ldy, float* a, int32_t lda, float* pooled, int32_t ldp, int32_t B, int32_t H, int32_t W,
+                      int32_t C, const float* scale, const float* shift, int32_t relu, int32_t kh, int32_t kw, float* absmax_a,
+                      float* absmax_pooled, void* stream);
 int qea_maxpool_bwd(const float* x, int32_t ldx, const float* dy, int32_t lddy, float* dx, int32_t lddx, int32_t B,
                     int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t relu_mask, int32_t accumulate,
                     float* absmax_out, void* stream);

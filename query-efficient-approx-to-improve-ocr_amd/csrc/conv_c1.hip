@@ -45,13 +45,63 @@ __global__ void conv_c1_fwd_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+// Forward, fast path (W % 4 == 0, fewer than 2^31 pixels): a thread makes FOUR consecutive pixels x 4 channels from one 3 x 6 input
+// window, filter column and bias in registers, 32-bit index arithmetic.  (The one-pixel kernel above spends most of its time on
+// 64-bit divisions and on nine bounds-checked loads per 16 output bytes: 2.9 TB/s of stores on the CRNN's first layer.)
+template <int COLS>
+__global__ __launch_bounds__(256) void conv_c1_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int ldy, int B, int H, int W, int relu) {
+  constexpr int GPB = 256 / COLS;                          // pixel groups per block and iteration
+  const int ct = threadIdx.x % COLS;
+  f32x4 wr[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wr[t][k] = w[(ct * 4 + k) * 9 + t];
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ct * 4);
+  const unsigned W4 = (unsigned)W >> 2;
+  const unsigned groups = (unsigned)B * (unsigned)H * W4;
+  const unsigned gstride = gridDim.x * GPB;
+  for (unsigned g = blockIdx.x * GPB + threadIdx.x / COLS; g < groups; g += gstride) {
+    const unsigned row = g / W4;                           // b * H + ph
+    const int pw0 = (int)(g - row * W4) * 4;
+    const int ph = (int)(row % (unsigned)H);
+    const float* xr = x + (size_t)row * W;                 // this image row
+    float xv[3][6];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const bool rok = (unsigned)(ph + kh - 1) < (unsigned)H;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int iw = pw0 + c - 1;
+        xv[kh][c] = (rok && (unsigned)iw < (unsigned)W) ? xr[(kh - 1) * W + iw] : 0.f;
+      }
+    }
+    float* yo = y + ((size_t)row * W + pw0) * ldy + ct * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 acc = bv;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc += wr[kh * 3 + kw] * xv[kh][j + kw];     // (tap order of the one-pixel kernel: same bits)
+      if (relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(yo + (size_t)j * ldy) = acc;
+    }
+  }
+}
+
 // dW[co][tap] = sum_p dy[p][co] * x[p + tap]; db[co] = sum_p dy[p][co].
 // thread (rt, ct): 4 channels x (9 taps + bias) fp32 partials over <= ROWS_PER_THREAD pixels,
 // fp32 LDS tree over rt, fp64 across blocks (second kernel).
-constexpr int C1_ROWS_PER_THREAD = 32;
+// pixels per thread: 32 ... 128, chosen by c1_wgrad_geom so that large launches amortise the per-block LDS tree and small ones keep the grid full
 
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int lddy, int B, int H,
-                                                            int W, int Co, int rt_n, float* __restrict__ ws) {
+                                                            int W, int Co, int rt_n, int rows_per_thread, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float sacc[];  // [rt_n][10][Co]
   const int cols = Co / 4;
   const int ct = threadIdx.x % cols, rt = threadIdx.x / cols;
@@ -60,12 +110,23 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (rt < rt_n) {
-    const long long r0 = (long long)blockIdx.x * rt_n * C1_ROWS_PER_THREAD;
-    for (int j = 0; j < C1_ROWS_PER_THREAD; ++j) {
+    const long long r0 = (long long)blockIdx.x * rt_n * rows_per_thread;
+    // (ph, pw) of the first pixel by division, then advanced by rt_n pixels per step (no 64-bit divisions in the loop)
+    int pw = (int)((r0 + rt) % W);
+    int ph = (int)(((r0 + rt) / W) % H);
+    const int dph = rt_n / W, dpw = rt_n - dph * W;
+    for (int j = 0; j < rows_per_thread; ++j) {
       const long long pix = r0 + (long long)j * rt_n + rt;
       if (pix >= M) break;
-      const int pw = (int)(pix % W);
-      const int ph = (int)((pix / W) % H);
+      if (j) {
+        pw += dpw;
+        ph += dph;
+        if (pw >= W) {
+          pw -= W;
+          ++ph;
+        }
+        ph = ph >= H ? ph % H : ph;
+      }
       const float* xb = x + (pix - (long long)ph * W - pw);
       const f32x4 g = *reinterpret_cast<const f32x4*>(dy + pix * lddy + ct * 4);
 #pragma unroll
@@ -152,6 +213,69 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
   (void)Co;
 }
 
+// Input gradient, tiled form: a workgroup owns an 8 x 64 pixel tile.  Phase 1: every pixel of the 10 x 66 halo reads its dy row ONCE
+// (COLS lanes x float4) and leaves the nine per-tap channel sums T[pixel][tap] = sum_co dy[pixel][co] w[co][tap] in LDS; phase 2: an
+// output pixel adds its nine neighbours' T.  (The per-pixel kernel above reads every dy row nine times through L1 and divides 64-bit
+// indices per element: 1.2 ms for the CRNN's first layer at B = 2048 against 0.45 ms of HBM time.)
+constexpr int C1D_TH = 8, C1D_TW = 64, C1D_HW = C1D_TW + 2, C1D_HP = (C1D_TH + 2) * C1D_HW;
+template <int COLS>
+__global__ __launch_bounds__(256) void conv_c1_dgrad_tile_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int H, int W, int tiles_x, int tiles_y, int accumulate) {
+  __shared__ float T[C1D_HP * 9];
+  __shared__ __attribute__((aligned(16))) float Wl[COLS * 9 * 4];   // [float4 column][tap][4 channels]
+  for (int e = threadIdx.x; e < COLS * 36; e += 256) {
+    const int k = e & 3, t = (e >> 2) % 9, c4 = e / 36;
+    Wl[e] = w[(c4 * 4 + k) * 9 + t];
+  }
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int x0 = tx * C1D_TW, y0 = ty * C1D_TH;
+  const float* dyb = dy + (size_t)b * H * W * lddy;
+  __syncthreads();
+  // ONE LANE PER HALO PIXEL: it reads the pixel's whole dy row (COLS float4; the 64 rows of a wave are one contiguous 16 KB range
+  // that stays in L1 across the COLS loads) against filter columns broadcast from LDS — no cross-lane reduction (the first tiled
+  // form gave a pixel to COLS lanes and all-reduced nine sums through 36 shuffles: 1003 us, hardly better than the 1193 of the
+  // per-pixel kernel)
+  for (int hq = threadIdx.x; hq < C1D_HP; hq += 256) {
+    const int hy = hq / C1D_HW, hx = hq - hy * C1D_HW;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    float d[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) d[t] = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      const float* row = dyb + ((size_t)iy * W + ix) * lddy;
+#pragma unroll 4
+      for (int c4 = 0; c4 < COLS; ++c4) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(row + c4 * 4);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(Wl + (c4 * 9 + t) * 4);
+          d[t] += g[0] * wv[0] + g[1] * wv[1] + g[2] * wv[2] + g[3] * wv[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) T[hq * 9 + t] = d[t];
+  }
+  __syncthreads();
+  float* dxb = dx + (size_t)b * H * W;
+  for (int q = threadIdx.x; q < C1D_TH * C1D_TW; q += 256) {
+    const int qy = q / C1D_TW, qx = q - qy * C1D_TW;
+    const int oy = y0 + qy, ox = x0 + qx;
+    if (oy >= H || ox >= W) continue;
+    float sacc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) sacc += T[((qy + 2 - kh) * C1D_HW + qx + 2 - kw) * 9 + kh * 3 + kw];   // halo pixel (qy + 1 + (1 - kh), qx + 1 + (1 - kw))
+    float* o = dxb + (size_t)oy * W + ox;
+    *o = accumulate ? *o + sacc : sacc;
+  }
+}
+
 // ---- UNet head ----
 template <int COLS>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
@@ -232,31 +356,46 @@ extern "C" int qea_conv_c1_fwd(const float* x, const float* w, const float* bias
                                int32_t Co, int32_t relu, void* stream) {
   QEA_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Co > 0 && Co % 4 == 0 && ldy % 4 == 0 && ldy >= Co, "qea_conv_c1_fwd: bad arguments");
   const long long n = (long long)B * H * W * (Co / 4);
+  if (W % 4 == 0 && (long long)B * H * W < 0x7fffffffLL && (Co == 32 || Co == 64 || Co == 128) && ((uintptr_t)y & 15) == 0 &&
+      (!bias || ((uintptr_t)bias & 15) == 0)) {
+    const int cols = Co / 4;
+    const long long groups = (long long)B * H * (W / 4);
+    const int grid = (int)((groups + 256 / cols - 1) / (256 / cols) > 16384 ? 16384 : (groups + 256 / cols - 1) / (256 / cols));
+    hipStream_t s = (hipStream_t)stream;
+    if (Co == 32) hipLaunchKernelGGL(conv_c1_fwd4_kernel<8>, dim3(grid), dim3(256), 0, s, x, w, bias, y, ldy, B, H, W, relu);
+    else if (Co == 64) hipLaunchKernelGGL(conv_c1_fwd4_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, bias, y, ldy, B, H, W, relu);
+    else hipLaunchKernelGGL(conv_c1_fwd4_kernel<32>, dim3(grid), dim3(256), 0, s, x, w, bias, y, ldy, B, H, W, relu);
+    QEA_CHECK_LAUNCH();
+    return QEA_OK;
+  }
   hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(grid_for(n, 8192)), dim3(256), (size_t)Co * 9 * sizeof(float), (hipStream_t)stream, x, w, bias, y,
                      ldy, B, H, W, Co, relu);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }
 
-static int c1_wgrad_geom(long long M, int Co, int* rt_n) {
+static int c1_wgrad_geom(long long M, int Co, int* rt_n, int* rows_per_thread) {
   const int cols = Co / 4;
   *rt_n = 256 / cols;
-  const long long per_block = (long long)(*rt_n) * C1_ROWS_PER_THREAD;
+  long long rpt = M / ((long long)(*rt_n) * 4096);         // about 4096 blocks when there is that much work
+  rpt = rpt < 32 ? 32 : (rpt > 128 ? 128 : rpt);
+  *rows_per_thread = (int)rpt;
+  const long long per_block = (long long)(*rt_n) * rpt;
   return (int)((M + per_block - 1) / per_block);
 }
 
 extern "C" size_t qea_conv_c1_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Co) {
   if (B <= 0 || H <= 0 || W <= 0 || Co <= 0 || Co % 4 || Co / 4 > 256) return 0;
-  int rt;
-  const int grid = c1_wgrad_geom((long long)B * H * W, Co, &rt);
+  int rt, rpt;
+  const int grid = c1_wgrad_geom((long long)B * H * W, Co, &rt, &rpt);
   return (size_t)grid * 10 * Co * sizeof(float);
 }
 
 extern "C" int qea_conv_c1_wgrad(const float* x, const float* dy, int32_t lddy, float* dw, float* db, int32_t B, int32_t H, int32_t W,
                                  int32_t Co, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   QEA_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && Co > 0 && Co % 4 == 0 && Co / 4 <= 256 && lddy % 4 == 0, "qea_conv_c1_wgrad: bad arguments");
-  int rt;
-  const int grid = c1_wgrad_geom((long long)B * H * W, Co, &rt);
+  int rt, rpt;
+  const int grid = c1_wgrad_geom((long long)B * H * W, Co, &rt, &rpt);
   QEA_REQUIRE(workspace && workspace_bytes >= (size_t)grid * 10 * Co * sizeof(float), "qea_conv_c1_wgrad: workspace too small");
   const size_t lds = (size_t)rt * 10 * Co * sizeof(float);
   QEA_REQUIRE(lds <= 160 * 1024, "qea_conv_c1_wgrad: Co too large for LDS");
@@ -266,7 +405,7 @@ extern "C" int qea_conv_c1_wgrad(const float* x, const float* dy, int32_t lddy, 
     attr = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(grid), dim3(256), lds, s, x, dy, lddy, B, H, W, Co, rt, (float*)workspace);
+  hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(grid), dim3(256), lds, s, x, dy, lddy, B, H, W, Co, rt, rpt, (float*)workspace);
   hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(qea_cdiv(10 * Co, 4)), dim3(256), 0, s, (const float*)workspace, grid, Co, dw, db,
                      accumulate);
   QEA_CHECK_LAUNCH();
@@ -279,6 +418,15 @@ extern "C" int qea_conv_c1_dgrad(const float* dy, int32_t lddy, const float* w, 
   const long long n = (long long)B * H * W * (Co / 4);
   const int grid = grid_for(n, 8192);
   hipStream_t s = (hipStream_t)stream;
+  const int tiles_x = qea_cdiv(W, C1D_TW), tiles_y = qea_cdiv(H, C1D_TH);
+  const long long tiles = (long long)B * tiles_x * tiles_y;
+  if (tiles < 0x7fffffffLL && (Co == 32 || Co == 64 || Co == 128) && ((uintptr_t)dy & 15) == 0) {
+    if (Co == 32) hipLaunchKernelGGL(conv_c1_dgrad_tile_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, s, dy, lddy, w, dx, H, W, tiles_x, tiles_y, accumulate);
+    else if (Co == 64) hipLaunchKernelGGL(conv_c1_dgrad_tile_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, s, dy, lddy, w, dx, H, W, tiles_x, tiles_y, accumulate);
+    else hipLaunchKernelGGL(conv_c1_dgrad_tile_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, s, dy, lddy, w, dx, H, W, tiles_x, tiles_y, accumulate);
+    QEA_CHECK_LAUNCH();
+    return QEA_OK;
+  }
   switch (Co) {
     case 32: hipLaunchKernelGGL(conv_c1_dgrad_kernel<8>, dim3(grid), dim3(256), 0, s, dy, lddy, w, dx, B, H, W, accumulate); break;
     case 64: hipLaunchKernelGGL(conv_c1_dgrad_kernel<16>, dim3(grid), dim3(256), 0, s, dy, lddy, w, dx, B, H, W, accumulate); break;

@@ -327,6 +327,46 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* 
   qea_amax_commit(am, amax);
 }
 
+// BatchNorm apply (+ReLU) AND the max-pool that follows it, one pass (model_unet.py:51-59: enc -> pool): a thread owns
+// one pooled pixel x 4 channels, reads its kh x kw window of y once, stores the kh*kw activations (the skip tensor / the operand of the
+// pool's backward) and their maximum.  Same fused multiply-add as bn_apply_kernel, same scan order and NaN rule as maxpool_fwd_kernel:
+// both outputs are bit-identical to the two separate passes, which read the full-resolution activation a second time.
+__global__ void bn_apply_pool_kernel(const float* __restrict__ y, int ldy, float* __restrict__ a, int lda, float* __restrict__ pooled, int ldp,
+                                     int B, int H, int W, int C, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                     int kh, int kw, float* __restrict__ amax_a, float* __restrict__ amax_p) {
+  const int OH = H / kh, OW = W / kw, cols = C / 4;
+  const long long n = (long long)B * OH * OW * cols;
+  float am = 0.f, pm = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ct = (int)(i % cols);
+    const long long op = i / cols;
+    const int ow = (int)(op % OW);
+    const long long orow = op / OW;                         // b * OH + oh
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ct * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ct * 4);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int i2 = 0; i2 < kh; ++i2)
+      for (int j2 = 0; j2 < kw; ++j2) {
+        const long long ip = (orow * kh + i2) * W + ow * kw + j2;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + ip * ldy + ct * 4);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[k] = bn_affine(v[k], sc[k], sh[k]);
+          if (relu) o[k] = fmaxf(o[k], 0.f);
+          am = qea_amax_acc(am, o[k]);
+          m[k] = (o[k] > m[k] || o[k] != o[k]) ? o[k] : m[k];
+        }
+        *reinterpret_cast<f32x4*>(a + ip * lda + ct * 4) = o;
+      }
+    *reinterpret_cast<f32x4*>(pooled + op * ldp + ct * 4) = m;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pm = qea_amax_acc(pm, m[k]);
+  }
+  qea_amax_commit(am, amax_a);
+  qea_amax_commit(pm, amax_p);
+}
+
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, float* __restrict__ dx,
                                    int lddx, int B, int H, int W, int C, int kh, int kw, int relu_mask, int accumulate,
                                    float* __restrict__ amax) {
@@ -582,6 +622,19 @@ extern "C" int qea_maxpool_fwd(const float* x, int32_t ldx, float* y, int32_t ld
               "qea_maxpool_fwd: bad arguments (H,W must be multiples of the window; C, ld multiples of 4)");
   const long long n = (long long)B * (H / kh) * (W / kw) * (C / 4);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, kh, kw, absmax_out);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_bn_apply_pool(const float* y, int32_t ldy, float* a, int32_t lda, float* pooled, int32_t ldp, int32_t B, int32_t H, int32_t W,
+                                 int32_t C, const float* scale, const float* shift, int32_t relu, int32_t kh, int32_t kw, float* absmax_a,
+                                 float* absmax_pooled, void* stream) {
+  QEA_REQUIRE(y && a && pooled && scale && shift && B > 0 && C > 0 && C % 4 == 0 && kh > 0 && kw > 0 && H > 0 && W > 0 && H % kh == 0 && W % kw == 0 &&
+                  ldy % 4 == 0 && lda % 4 == 0 && ldp % 4 == 0,
+              "qea_bn_apply_pool: bad arguments (H,W must be multiples of the window; C, ld multiples of 4)");
+  const long long n = (long long)B * (H / kh) * (W / kw) * (C / 4);
+  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, ldy, a, lda, pooled, ldp, B, H, W, C, scale, shift,
+                     relu, kh, kw, absmax_a, absmax_pooled);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

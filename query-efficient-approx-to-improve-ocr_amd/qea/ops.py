@@ -415,6 +415,12 @@ def colsum(x, ldx, M, C_, out, accumulate=False):
     _lib.check(_lib.lib().qea_colsum(_ptr(x), ldx, M, C_, _ptr(out), int(accumulate), wp, wn, _stream()), "qea_colsum")
 
 
+def bn_apply_pool(y, ldy, a, lda, pooled, ldp, B, H, W, C_, scale, shift, kh, kw, relu=True, amax=None, pooled_amax=None):
+    """bn_apply + maxpool_fwd in one pass over y (bit-identical to the two calls)"""
+    _lib.check(_lib.lib().qea_bn_apply_pool(_ptr(y), ldy, _ptr(a), lda, _ptr(pooled), ldp, B, H, W, C_, _ptr(scale), _ptr(shift), int(relu), kh, kw,
+                                            _ptr(amax), _ptr(pooled_amax), _stream()), "qea_bn_apply_pool")
+
+
 def maxpool_fwd(x, ldx, y, ldy, B, H, W, C_, kh, kw, amax=None):
     _lib.check(_lib.lib().qea_maxpool_fwd(_ptr(x), ldx, _ptr(y), ldy, B, H, W, C_, kh, kw, _ptr(amax), _stream()), "qea_maxpool_fwd")
 

@@ -20,6 +20,7 @@ from .params import ensure_flat
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 FUSE_EVAL_BN = True   # tests flip this to compare the fused inference epilogue with the two-pass form
+FUSE_BN_POOL = True   # tests flip this: the encoder's BatchNorm apply + ReLU and its 2x2 max-pool in one pass (qea_bn_apply_pool)
 
 
 class _Block:
@@ -50,11 +51,21 @@ class UNetEngine:
         Bf = dict(self.m.named_buffers())
         return P, Bf
 
-    def _conv_bn_relu(self, P, Bf, blk, i, x, ldx, cin, B, H, W, out, ldo, training, saved, groups=1, x_amax=None, out_amax=None):
+    def _conv_bn_relu(self, P, Bf, blk, i, x, ldx, cin, B, H, W, out, ldo, training, saved, groups=1, x_amax=None, out_amax=None, pool=None):
         """x [B,H,W,cin] (pixel stride ldx) -> conv -> BN -> ReLU -> out (pixel stride ldo).
         groups > 1 (train mode): batch statistics per group of B / groups consecutive images, running statistics updated once
         per group in order — what `groups` sequential forward calls of the reference do (one document per call,
-        train_nn_patch.py:318-321)."""
+        train_nn_patch.py:318-321).
+        pool = (pooled [B*(H/2)*(W/2)][cout], its abs-max slot): the 2x2 max-pool of the block output (model_unet.py:52-59) leaves with
+        the BatchNorm apply in ONE pass (FUSE_BN_POOL) where there is such a pass; returns True when it did, else the caller pools."""
+        def apply(yv, ov, rows, sc, sh, b0, nb):
+            if pool is not None and FUSE_BN_POOL:
+                pv = pool[0][b0 * (H // 2) * (W // 2):(b0 + nb) * (H // 2) * (W // 2)]
+                ops.bn_apply_pool(yv, cout, ov, ldo, pv, cout, nb, H, W, cout, sc, sh, 2, 2, relu=True, amax=out_amax, pooled_amax=pool[1])
+            else:
+                ops.bn_apply(yv, cout, ov, ldo, rows, cout, sc, sh, relu=True, amax=out_amax)
+            return pool is not None and FUSE_BN_POOL
+
         dev = x.device
         cout = blk.cout
         M = B * H * W
@@ -67,7 +78,7 @@ class UNetEngine:
                               None, coef[0], coef[1], coef[2], coef[3])
             ops.conv_igemm(x, w, out, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=ldo,
                            scale=coef[2], bias=coef[3], relu=True, w_src=("fwd", w), x_amax=x_amax, y_amax=out_amax)
-            return
+            return False
         y = torch.empty(M, cout, device=dev)
         fused = None
         if cin == 1:
@@ -87,10 +98,10 @@ class UNetEngine:
                 yg = y[g * Mg:(g + 1) * Mg]
                 ops.bn_train_stats(yg, cout, Mg, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[g, 0], coef[g, 1], coef[g, 2], coef[g, 3],
                                    stat64[g] if stat64 is not None else None)
-                ops.bn_apply(yg, cout, out[g * Mg:(g + 1) * Mg], ldo, Mg, cout, coef[g, 2], coef[g, 3], relu=True, amax=out_amax)
+                pooled_here = apply(yg, out[g * Mg:(g + 1) * Mg], Mg, coef[g, 2], coef[g, 3], g * (B // groups), B // groups)
             if saved is not None:
                 saved.append((y, coef, stat64))
-            return
+            return pooled_here
         coef = torch.empty(4, cout, device=dev)  # mean, invstd, scale, shift
         stat64 = None
         if training:
@@ -102,9 +113,10 @@ class UNetEngine:
                 ops.bn_train_stats(y, cout, M, cout, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv, coef[0], coef[1], coef[2], coef[3], stat64)
         else:
             ops.bn_eval_coeff(cout, gamma, beta, rm, rv, BN_EPS, None, coef[0], coef[1], coef[2], coef[3])
-        ops.bn_apply(y, cout, out, ldo, M, cout, coef[2], coef[3], relu=True, amax=out_amax)
+        pooled_here = apply(y, out, M, coef[2], coef[3], 0, B)
         if saved is not None:
             saved.append((y, coef, stat64))
+        return pooled_here
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, training, need_grad, groups=1):
@@ -125,16 +137,17 @@ class UNetEngine:
         pool = ops.amax_pool(dev)
         slot = (lambda: pool.slot()) if pool is not None else (lambda: None)
 
-        def run_block(blk, xin, ldx, cin, h, w, out, ldo, xin_amax, out_amax):
+        def run_block(blk, xin, ldx, cin, h, w, out, ldo, xin_amax, out_amax, pool=None):
             saved = [] if need_grad else None
             a1 = torch.empty(B * h * w, blk.cout, device=dev)
             a1_amax = slot()
             self._conv_bn_relu(P, Bf, blk, 1, xin, ldx, cin, B, h, w, a1, blk.cout, training, saved, groups, xin_amax, a1_amax)
-            self._conv_bn_relu(P, Bf, blk, 2, a1, blk.cout, blk.cout, B, h, w, out, ldo, training, saved, groups, a1_amax, out_amax)
+            pooled_here = self._conv_bn_relu(P, Bf, blk, 2, a1, blk.cout, blk.cout, B, h, w, out, ldo, training, saved, groups, a1_amax, out_amax, pool)
             if need_grad:
                 ctx["blocks"][blk.mod] = {"xin": xin, "ldx": ldx, "cin": cin, "h": h, "w": w, "a1": a1, "out": out, "ldo": ldo,
                                           "y1": saved[0][0], "coef1": saved[0][1], "st1": saved[0][2], "y2": saved[1][0],
                                           "coef2": saved[1][1], "st2": saved[1][2], "xin_amax": xin_amax, "a1_amax": a1_amax}
+            return pooled_here
 
         # encoder: level l has c = f*2^(l-1) channels at (H,W)/2^(l-1); its output goes to cat_l[:, c:2c]
         cats, cat_amax = {}, {}
@@ -146,10 +159,10 @@ class UNetEngine:
             cats[l] = (cat, h, w, c)
             cat_amax[l] = slot()                               # shared by the skip half (BatchNorm apply) and the up half (transposed conv)
             skip = cat[:, c:]
-            run_block(blk, xin, ldx, cin, h, w, skip, 2 * c, xin_amax, cat_amax[l])
             pooled = torch.empty(B * (h // 2) * (w // 2), c, device=dev)
-            xin_amax = slot()
-            ops.maxpool_fwd(skip, 2 * c, pooled, c, B, h, w, c, 2, 2, amax=xin_amax)
+            xin_in, xin_amax = xin_amax, slot()
+            if not run_block(blk, xin, ldx, cin, h, w, skip, 2 * c, xin_in, cat_amax[l], pool=(pooled, xin_amax)):
+                ops.maxpool_fwd(skip, 2 * c, pooled, c, B, h, w, c, 2, 2, amax=xin_amax)
             xin, ldx, cin = pooled, c, c
             h, w = h // 2, w // 2
         d = torch.empty(B * h * w, self.bott.cout, device=dev)

@@ -190,10 +190,14 @@ def test_convtranspose_fwd_and_dgrad():
 
 
 # ----------------------------------------------------------------------------- C_in = 1 convs, head
-@pytest.mark.parametrize("Co,relu,bias", [(32, False, False), (64, True, True)])
-def test_conv_c1(Co, relu, bias):
+@pytest.mark.parametrize("Co,relu,bias,Hh,Ww", [(32, False, False, 32, 128), (64, True, True, 32, 128), (64, True, True, 12, 48), (32, False, True, 9, 30),
+                                                (128, True, False, 16, 200)])
+def test_conv_c1(Co, relu, bias, Hh, Ww):
+    """C_in = 1 convolutions (UNet enc1conv1, CRNN conv1; /root/reference/models/model_unet.py:85, model_crnn.py:37): forward (4-pixel
+    groups when W % 4 == 0, else the one-pixel kernel), weight / bias gradient, input gradient (8 x 64 tiles; partial tiles at 12 x 48,
+    9 x 30 and 16 x 200) against fp64 autograd"""
     from qea import ops
-    B, Hh, Ww = 3, 32, 128
+    B = 3
     g = torch.Generator().manual_seed(Co)
     x = torch.rand(B, 1, Hh, Ww, generator=g).double().requires_grad_()
     w = torch.randn(Co, 1, 3, 3, generator=g).double().requires_grad_()
@@ -216,6 +220,8 @@ def test_conv_c1(Co, relu, bias):
     dx = torch.empty(B, Hh, Ww, device="cuda")
     ops.conv_c1_dgrad(dyd, Co, wd, dx, B, Hh, Ww, Co)
     assert rel_err(dx.cpu(), x.grad.reshape(B, Hh, Ww)) < 1e-5
+    ops.conv_c1_dgrad(dyd, Co, wd, dx, B, Hh, Ww, Co, accumulate=True)
+    assert rel_err(dx.cpu(), 2 * x.grad.reshape(B, Hh, Ww)) < 1e-5
 
 
 def test_head_fwd_bwd():

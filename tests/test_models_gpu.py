@@ -478,3 +478,42 @@ def test_unet_inference_fused_bn_epilogue_is_bit_identical():
         finally:
             unet_engine.FUSE_EVAL_BN = True
     assert torch.equal(outs[0], outs[1])
+
+
+def test_bn_apply_and_pool_in_one_pass_is_bit_identical():
+    """qea_bn_apply_pool (the encoder's BatchNorm apply + ReLU and the 2x2 max-pool behind it in one pass, models/model_unet.py:52-59)
+    against the two separate launches: kernel level (both outputs and both abs-max slots, NaN and tie cases, (2,1) windows, strided
+    buffers) and through the UNet in train mode (outputs, every gradient, running statistics; one and two BatchNorm groups)."""
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea import ops, unet_engine
+    g = torch.Generator().manual_seed(3)
+    for (B, Hh, Ww, Cc, kh, kw) in ((3, 8, 32, 64, 2, 2), (2, 6, 10, 32, 2, 1), (1, 2, 2, 4, 2, 2)):
+        y = torch.randn(B, Hh, Ww, Cc + 8, generator=g).cuda()
+        y[0, 0, 0, 0] = float("nan")
+        y[0, 1, 1, 1] = y[0, 0, 1, 1] = y[0, 1, 0, 1] = y[0, 0, 0, 1] = 0.5                 # a four-way tie
+        sc, sh = (torch.rand(Cc, generator=g) + 0.5).cuda(), torch.randn(Cc, generator=g).cuda()
+        a0 = torch.full((B, Hh, Ww, 2 * Cc), -7.0, device="cuda")
+        a1 = a0.clone()
+        p0 = torch.empty(B, Hh // kh, Ww // kw, Cc, device="cuda")
+        p1 = torch.empty_like(p0)
+        am = torch.zeros(4, device="cuda")
+        ops.bn_apply(y, Cc + 8, a0[..., Cc:], 2 * Cc, B * Hh * Ww, Cc, sc, sh, relu=True, amax=am[0:1])
+        ops.maxpool_fwd(a0[..., Cc:], 2 * Cc, p0, Cc, B, Hh, Ww, Cc, kh, kw, amax=am[1:2])
+        ops.bn_apply_pool(y, Cc + 8, a1[..., Cc:], 2 * Cc, p1, Cc, B, Hh, Ww, Cc, sc, sh, kh, kw, relu=True, amax=am[2:3], pooled_amax=am[3:4])
+        torch.cuda.synchronize()
+        assert torch.equal(a0.view(torch.int32), a1.view(torch.int32)) and torch.equal(p0.view(torch.int32), p1.view(torch.int32))
+        assert am[0].item() == am[2].item() and am[1].item() == am[3].item()
+    for groups in (1, 2):
+        res = []
+        for fuse in (True, False):
+            unet_engine.FUSE_BN_POOL = fuse
+            try:
+                net = _load(UNet(), mo.unet_state_shapes, 1).train()
+                x = H.synth_images(4, 21).cuda()
+                out = net(x, bn_groups=groups)
+                (out * torch.linspace(0.5, 1.5, out.numel(), device="cuda").view_as(out)).sum().backward()
+                res.append([out.detach().clone()] + [p.grad.clone() for p in net.parameters()] + [b.clone() for b in net.buffers()])
+            finally:
+                unet_engine.FUSE_BN_POOL = True
+        assert all(torch.equal(u, v) for u, v in zip(*res))
