@@ -286,6 +286,11 @@ int qea_filter_flip_transpose(const float* w, float* wt, int32_t Co, int32_t Ci,
  * (db may be NULL); dgrad: dx[B,H,W] (+)= sum_{tap,co} dy * w. */
 int qea_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y, int32_t ldy, int32_t B, int32_t H,
                     int32_t W, int32_t Co, int32_t relu, void* stream);
+/* ABI v7 (additive).  qea_conv_c1_fwd followed by the 2x2 max-pool in one pass (CRNN conv1 -> ReLU -> max_pool2d(2,2),
+ * model_crnn.py:48): y (full resolution: the pool's backward reads it) and pooled [B,H/2,W/2,Co], bit-identical to the two calls.
+ * Needs H % 2 == 0, W % 4 == 0, Co in {32, 64, 128}; absmax_pooled as qea_maxpool_fwd's absmax_out. */
+int qea_conv_c1_fwd_pool(const float* x, const float* w, const float* bias, float* y, int32_t ldy, float* pooled, int32_t ldp, int32_t B,
+                         int32_t H, int32_t W, int32_t Co, int32_t relu, float* absmax_pooled, void* stream);
 size_t qea_conv_c1_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Co);
 int qea_conv_c1_wgrad(const float* x, const float* dy, int32_t lddy, float* dw, float* db, int32_t B, int32_t H,
                       int32_t W, int32_t Co, int32_t accumulate, void* workspace, size_t workspace_bytes,

@@ -15,6 +15,7 @@ from .params import ensure_flat
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+FUSE_POOL = True      # tests flip this: conv1 + ReLU + pool and BatchNorm2 apply + ReLU + pool as one pass each (same bits)
 HID = 256
 
 # (name, cin, cout, relu fused in the conv epilogue, pool after (kh,kw) or None)
@@ -53,11 +54,14 @@ class CRNNEngine:
         amx = {}
         # conv1 (C_in = 1) + ReLU, pool 2x2
         a1 = torch.empty(B * H * W, 64, device=dev)
-        ops.conv_c1_fwd(x, P[c + "conv1.weight"], P[c + "conv1.bias"], a1, 64, B, H, W, 64, relu=True)
         h, w = H // 2, W // 2
         p1 = torch.empty(B * h * w, 64, device=dev)
         amx["p1"] = slot()
-        ops.maxpool_fwd(a1, 64, p1, 64, B, H, W, 64, 2, 2, amax=amx["p1"])
+        # conv1 + ReLU + max-pool in one pass where the shape allows (FUSE_POOL; the same bits as the two launches)
+        if not (FUSE_POOL and ops.conv_c1_fwd_pool(x, P[c + "conv1.weight"], P[c + "conv1.bias"], a1, 64, p1, 64, B, H, W, 64, relu=True,
+                                                   pooled_amax=amx["p1"])):
+            ops.conv_c1_fwd(x, P[c + "conv1.weight"], P[c + "conv1.bias"], a1, 64, B, H, W, 64, relu=True)
+            ops.maxpool_fwd(a1, 64, p1, 64, B, H, W, 64, 2, 2, amax=amx["p1"])
         acts = {"a1": a1, "p1": p1}
         cur, ccur, cur_name = p1, 64, "p1"
         dims = {"conv1": (H, W)}
@@ -99,15 +103,26 @@ class CRNNEngine:
                 else:
                     ops.bn_eval_coeff(512, P[c + bn + ".weight"], P[c + bn + ".bias"], Bf[c + bn + ".running_mean"],
                                       Bf[c + bn + ".running_var"], BN_EPS, None, coef[gi, 0], coef[gi, 1], coef[gi, 2], coef[gi, 3])
-                ops.bn_apply(yg, 512, ag, 512, Mg, 512, coef[gi, 2], coef[gi, 3], relu=True, amax=amx["a" + name[-1]])
+                if name == "conv6" and FUSE_POOL:
+                    # BatchNorm apply + ReLU + the (2,1) max-pool behind it in one pass (bit-identical; p6 is allocated here)
+                    if gi == 0:
+                        p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
+                        amx["p6"] = slot()
+                    bg = B // G
+                    ops.bn_apply_pool(yg, 512, ag, 512, p6[gi * bg * (h // 2) * w:(gi + 1) * bg * (h // 2) * w], 512, bg, h, w, 512, coef[gi, 2],
+                                      coef[gi, 3], 2, 1, relu=True, amax=amx["a" + name[-1]], pooled_amax=amx["p6"])
+                else:
+                    ops.bn_apply(yg, 512, ag, 512, Mg, 512, coef[gi, 2], coef[gi, 3], relu=True, amax=amx["a" + name[-1]])
             acts["y" + name[-1]], acts["coef" + name[-1]], acts["a" + name[-1]], acts["st" + name[-1]] = y, coef, a, stat64
             dims[name] = (h, w)
             cur, cur_name = a, "a" + name[-1]
         if bn_training:
             fs.ibuf.add_(groups)
-        p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
-        amx["p6"], amx["seq"] = slot(), slot()
-        ops.maxpool_fwd(cur, 512, p6, 512, B, h, w, 512, 2, 1, amax=amx["p6"])
+        amx["seq"] = slot()
+        if not FUSE_POOL:
+            p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
+            amx["p6"] = slot()
+            ops.maxpool_fwd(cur, 512, p6, 512, B, h, w, 512, 2, 1, amax=amx["p6"])
         acts["p6"] = p6
         h6, w6 = h // 2, w
         T = w6 - 1

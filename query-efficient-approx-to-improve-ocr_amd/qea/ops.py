@@ -444,6 +444,15 @@ def conv_c1_fwd(x, w, bias, y, ldy, B, H, W, Co, relu=False):
                "qea_conv_c1_fwd")
 
 
+def conv_c1_fwd_pool(x, w, bias, y, ldy, pooled, ldp, B, H, W, Co, relu=False, pooled_amax=None):
+    """conv_c1_fwd + maxpool_fwd(2, 2) in one pass (bit-identical); False when the shape is not taken (the caller then runs the two)"""
+    if H % 2 or W % 4 or Co not in (32, 64, 128):
+        return False
+    _lib.check(_lib.lib().qea_conv_c1_fwd_pool(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), ldy, _ptr(pooled), ldp, B, H, W, Co, int(relu),
+                                               _ptr(pooled_amax), _stream()), "qea_conv_c1_fwd_pool")
+    return True
+
+
 def conv_c1_wgrad(x, dy, lddy, dw, db, B, H, W, Co, accumulate=False):
     L = _lib.lib()
     ws = workspace(L.qea_conv_c1_wgrad_workspace_bytes(B, H, W, Co), x.device)

@@ -517,3 +517,42 @@ def test_bn_apply_and_pool_in_one_pass_is_bit_identical():
             finally:
                 unet_engine.FUSE_BN_POOL = True
         assert all(torch.equal(u, v) for u, v in zip(*res))
+
+
+def test_crnn_fused_pools_are_bit_identical():
+    """qea_conv_c1_fwd_pool (conv1 + ReLU + max_pool2d(2,2), models/model_crnn.py:48) and qea_bn_apply_pool behind BatchNorm2
+    (models/model_crnn.py:53-54) against the separate launches: kernel level (both outputs, the pooled abs-max, NaN in the input) and
+    through the CRNN (log-probs, input gradient, every parameter gradient, running statistics; train-mode BN, one and two groups)."""
+    from models.model_crnn import CRNN
+    from oracle import model_oracle as mo
+    from qea import crnn_engine, ops
+    g = torch.Generator().manual_seed(11)
+    for (B, Hh, Ww, Co) in ((3, 32, 128, 64), (2, 6, 12, 32), (1, 2, 4, 128)):
+        x = torch.rand(B, Hh, Ww, generator=g).cuda()
+        x[0, 1, 2] = float("nan")
+        w, b = torch.randn(Co, 9, generator=g).cuda(), torch.randn(Co, generator=g).cuda()
+        y0 = torch.empty(B, Hh, Ww, Co, device="cuda")
+        y1 = torch.empty_like(y0)
+        p0 = torch.empty(B, Hh // 2, Ww // 2, Co, device="cuda")
+        p1 = torch.empty_like(p0)
+        am = torch.zeros(2, device="cuda")
+        ops.conv_c1_fwd(x, w, b, y0, Co, B, Hh, Ww, Co, relu=True)
+        ops.maxpool_fwd(y0, Co, p0, Co, B, Hh, Ww, Co, 2, 2, amax=am[0:1])
+        assert ops.conv_c1_fwd_pool(x, w, b, y1, Co, p1, Co, B, Hh, Ww, Co, relu=True, pooled_amax=am[1:2])
+        torch.cuda.synchronize()
+        assert torch.equal(y0.view(torch.int32), y1.view(torch.int32)) and torch.equal(p0.view(torch.int32), p1.view(torch.int32))
+        assert am[0].item() == am[1].item()
+    assert not ops.conv_c1_fwd_pool(x, w, b, y1, Co, p1, Co, 1, 3, 4, Co)               # odd height: the caller runs the two launches
+    for groups in (1, 2):
+        res = []
+        for fuse in (True, False):
+            crnn_engine.FUSE_POOL = fuse
+            try:
+                net = _load(CRNN(95, False), mo.crnn_state_shapes, 2).train()
+                x = H.synth_images(4, 5).cuda().requires_grad_()
+                lp = net(x, replica_groups=groups)
+                (lp * torch.linspace(0.5, 1.5, lp.numel(), device="cuda").view_as(lp)).sum().backward()
+                res.append([lp.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()] + [bf.clone() for bf in net.buffers()])
+            finally:
+                crnn_engine.FUSE_POOL = True
+        assert all(torch.equal(u, v) for u, v in zip(*res))
