@@ -140,12 +140,24 @@ typedef struct qea_conv_desc {
   /* ABI v6: zero-filled float slot receiving max |v| of the finite values this launch STORES (see qea_bn_apply's absmax_out);
    * honoured by the LDS-halo kernel (tile 24) and by the generic split tiles 20-23 / 25 (incl. QEA_OUT_CONVT); NULL = off. */
   float* y_absmax;
+  /* ABI v7: the max-pool that FOLLOWS the layer, fused into the epilogue of the LDS-halo kernel (nothing in the reference: fn.max_pool2d
+   * after relu(conv), models/model_crnn.py:49,51; self.poolN(encN), models/model_unet.py:52-59 in the inference pass).  pool_y non-NULL:
+   * besides y the launch writes pool_y [B, H/2, W/pool_kw, N] (pixel stride ldpool) = max over 2 x pool_kw windows of the stored
+   * values, first maximum in scan order / NaN propagating as qea_maxpool_fwd — bit-identical to that call on y — and folds its
+   * abs-max into pool_absmax (zero-filled slot, may be NULL).  Only where qea_conv_igemm_can_pool(d, pool_kw) returns 1 and the fp16
+   * operands (x_absmax, w_frag_planes of qea_pack_frag_planes_f16) are given; anything else is QEA_ERR_INVALID. */
+  float* pool_y;
+  int32_t ldpool;
+  int32_t pool_kw;
+  float* pool_absmax;
 } qea_conv_desc;
 
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
 /* 1 when qea_conv_igemm would run this launch on a split-bf16 tile (so that pre-split operands pay), else 0 */
 int qea_conv_igemm_uses_split_bf16(const qea_conv_desc* d);
 int qea_conv_igemm_stats_blocks(const qea_conv_desc* d);
+/* ABI v7: 1 when this launch (pool_y aside) has an LDS-halo instance with the fused 2 x kw max-pool (kw = 1 or 2) */
+int qea_conv_igemm_can_pool(const qea_conv_desc* d, int32_t kw);
 /* 1: the launch would run on the LDS-halo 3x3 kernel (tile 24) given w_frag_planes = qea_pack_frag_planes / _f16 of the filter;
  * 2 (ABI v7): it would run on the 1x1 LDS tile (tile 26) given x_absmax and w_frag_planes = qea_pack_frag_planes_f16_1x1; 0: neither */
 int qea_conv_igemm_wants_frag_planes(const qea_conv_desc* d);

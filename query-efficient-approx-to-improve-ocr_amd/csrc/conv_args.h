@@ -24,6 +24,10 @@ struct ConvArgs {
   const float* xmax;
   // producer-carried abs-max of the stored outputs (qea_conv_desc.y_absmax), or null
   float* yamax;
+  // fused max-pool of the stored outputs (LDS-halo kernel only): pooled tensor, its pixel stride, window width (height 2), abs-max slot
+  float* pool_y;
+  int ldpool, pool_kw;
+  float* pool_amax;
 };
 
 // Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,

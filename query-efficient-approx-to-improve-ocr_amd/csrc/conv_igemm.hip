@@ -982,12 +982,16 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
 // bound by the latency of their halo gather and stores, not by the MFMA pipe
 constexpr int halo_bf3_wgs(int cin, int cout, int npl) { return (npl == 2 && cout <= 64 && (cin == 32 || cout == 32) && QEA_HALO_NARROW_WGS == 3) ? 3 : 2; }
 
-template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3>
+// PKW != 0 (round 3): the max-pool that follows the layer leaves with the epilogue — window 2 x PKW over the STORED values (after scale /
+// bias / ReLU), scan order and NaN rule of maxpool_fwd_kernel, written to `pooled` (pixel stride ldp) next to the full-resolution
+// output; a row pair and, for PKW = 2, a pixel pair sit in one lane's accumulators (needs MI even).  No mask, no statistics.
+template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3, int PKW = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wgs(CIN, COUT, NPL), halo_bf3_wgs(CIN, COUT, NPL)))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
                                                                int Ntot, const float* __restrict__ mask, int ldmask, int total,
-                                                               const float* __restrict__ xmax, float* __restrict__ yamax) {
+                                                               const float* __restrict__ xmax, float* __restrict__ yamax,
+                                                               float* __restrict__ pooled, int ldp, float* __restrict__ pamax) {
   constexpr bool F16 = NPL == 2;
   typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
   constexpr bool SMALL = IMW != 0;
@@ -1001,6 +1005,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
   constexpr int SLOTS = CIN / 8;                        // 16-byte slots per pixel row (4 or 8)
   constexpr int PLANE = HP * CIN;                       // bf16 elements per plane
   static_assert(MI >= 1 && TH % WM == 0, "tile rows must split over the waves");
+  static_assert(PKW == 0 || (MI % 2 == 0 && !STATS && (PKW == 1 || PKW == 2)), "fused pooling: row pairs inside one wave, no statistics");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* As = reinterpret_cast<__bf16*>(smem);         // [NPL][HP][CIN] (16-bit elements: bf16, or fp16 when NPL == 2)
   float sx = 1.f, inv_x = 1.f, inv_w = 1.f;
@@ -1211,6 +1216,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
     const float esc = scale ? scale[n] : 1.f, ebi = bias ? bias[n] : 0.f;
     double st0 = 0.0, st1 = 0.0;
     float am = 0.f;
+    if constexpr (PKW != 0) {
+      float pm = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; i += 2) {
+        float vv[2][16];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            size_t prow;
+            bool live = true;
+            if (SMALL) {
+              const int img = ((i + ii) / IMH) * IPX + px / IMW;
+              prow = ((size_t)(cur.b + img) * IMH + (i + ii) % IMH) * IMW + px % IMW;
+              live = cur.b + img < B;
+            } else {
+              prow = (size_t)(cur.b * H + cur.y0 + wm * MI + i + ii) * W + cur.x0 + px;
+            }
+            float v = acc[i + ii][r];
+            if constexpr (F16) v = (v * inv_x) * inv_w;
+            if (scale && bias) v = __fmaf_rn(v, esc, ebi);
+            else if (scale) v *= esc;
+            else if (bias) v += ebi;
+            if (relu) v = fmaxf(v, 0.f);
+            vv[ii][r] = v;
+            if (!live) continue;
+            y[prow * ldy + n] = v;
+            am = qea_amax_acc(am, v);
+          }
+#pragma unroll
+        for (int r = 0; r < 16; r += PKW) {
+          const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;     // even when PKW == 2 (r even)
+          float m = -INFINITY;
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < PKW; ++jj) {
+              const float v = vv[ii][r + jj];
+              m = (v > m || v != v) ? v : m;
+            }
+          size_t prow;
+          bool live = true;
+          if (SMALL) {
+            const int img = (i / IMH) * IPX + px / IMW;
+            prow = ((size_t)(cur.b + img) * (IMH / 2) + (i % IMH) / 2) * (IMW / PKW) + (px % IMW) / PKW;
+            live = cur.b + img < B;
+          } else {
+            prow = ((size_t)cur.b * (H / 2) + (cur.y0 + wm * MI + i) / 2) * (W / PKW) + (cur.x0 + px) / PKW;
+          }
+          if (!live) continue;
+          pooled[prow * ldp + n] = m;
+          pm = qea_amax_acc(pm, m);
+        }
+      }
+      qea_amax_commit(pm, pamax);
+    } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -1240,6 +1302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
           st1 += (double)v * (double)v;
         }
       }
+    }
     }
     qea_amax_commit(am, yamax);
     if (STATS) {                                        // one partial per (pixel tile, wave row): [blocks][Ntot][2]
@@ -1321,10 +1384,10 @@ __global__ void pack_frag_planes_f16_kernel(const float* __restrict__ w, _Float1
   for (int p = 0; p < 2; ++p) *reinterpret_cast<f16x8*>(dst + ((((size_t)gst * 2 + p) * WNr + nj) * 64 + lane) * 8) = pl[p];
 }
 
-template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3>
+template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3, int PKW = 0>
 int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
   constexpr size_t lds = IMW ? (size_t)NPL * (TH + 1) * (32 / IMW) * (IMW + 2) * CIN * 2 : (size_t)NPL * (TH + 2) * 34 * CIN * 2;
-  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS, IMW, NPL>;
+  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS, IMW, NPL, PKW>;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr_rc != (int)hipSuccess) {
     qea_set_error("qea_conv_igemm(halo bf3): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
@@ -1348,8 +1411,16 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
   // (re-measured with the fp16 split and three workgroups per CU: persistent 0.779 / 1.431 ms against 0.750 / 1.331 one item each)
   const unsigned grid = (total > resident && COUT > 32) ? (unsigned)resident : (unsigned)total;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
-                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total, a.xmax, a.yamax);
+                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total, a.xmax, a.yamax, a.pool_y, a.ldpool, a.pool_amax);
   return QEA_OK;
+}
+
+// the instances with the fused max-pool (fp16 form, no statistics): the layers that are followed by a pool — CRNN conv2 (2x2) and conv4
+// (2x1), the second conv of the UNet encoder levels in the inference pass (BatchNorm + ReLU in the epilogue)
+template <int CIN, int COUT, int TH, int IMW = 0>
+int launch_halo_bf3_pool(const ConvArgs& a, hipStream_t s) {
+  if (a.pool_kw == 1) return launch_halo_bf3_<CIN, COUT, TH, false, IMW, 2, 1>(a, s);
+  return launch_halo_bf3_<CIN, COUT, TH, false, IMW, 2, 2>(a, s);
 }
 
 template <int CIN, int COUT, int TH, int IMW = 0>
@@ -1391,8 +1462,25 @@ long long halo_bf3_tiles(const qea_conv_desc* d) {
   return (long long)d->B * (d->H / (d->Cin == 32 ? 8 : 4)) * (d->W / 32);
 }
 
+// 1 when a launch of this shape has an instance with the fused max-pool (window 2 x kw) — given the fp16 operands
+bool halo_bf3_pool_shape(const qea_conv_desc* d, int kw) {
+  if (!halo_bf3_eligible(d) || d->mask || d->stats || d->H % 2 || (kw != 1 && kw != 2) || (kw == 2 && d->W % 2)) return false;
+  const int sm = halo_bf3_small(d);
+  if (sm == 16) return true;                             // <64,128,4,16>
+  if (sm) return false;
+  if (d->Cin == 32) return d->N == 32 && kw == 2;        // <32,32,8>
+  if (d->N == 64) return kw == 2;                        // <64,64,4>
+  return d->N % 128 == 0;                                // <64,128,4>: both windows
+}
+
 int launch_halo_bf3_any(const qea_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   const int sm = halo_bf3_small(d);
+  if (a.pool_y) {
+    if (sm == 16) return launch_halo_bf3_<64, 128, 4, false, 16, 2, 2>(a, s);
+    if (d->Cin == 32) return launch_halo_bf3_<32, 32, 8, false, 0, 2, 2>(a, s);
+    if (d->N == 64) return launch_halo_bf3_<64, 64, 4, false, 0, 2, 2>(a, s);
+    return launch_halo_bf3_pool<64, 128, 4>(a, s);
+  }
   if (sm == 16) return launch_halo_bf3<64, 128, 4, 16>(a, s);
   if (sm == 8) return launch_halo_bf3<64, 128, 4, 8>(a, s);
   if (d->Cin == 32) {
@@ -1544,9 +1632,20 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   a.wp = (const char*)d->w_planes;
   a.xp_zero = a.wp_zero = 0;
   a.stats = nullptr;
+  a.pool_y = nullptr;
+  a.ldpool = a.pool_kw = 0;
+  a.pool_amax = nullptr;
 
   hipStream_t s = (hipStream_t)stream;
   int tile = resolve_tile(d, a);
+  if (d->pool_y) {                                         // fused max-pool: only where qea_conv_igemm_can_pool says so, fp16 operands given
+    QEA_REQUIRE(tile == 24 && halo_bf3_pool_shape(d, d->pool_kw) && d->x_absmax && d->w_frag_planes && d->ldpool >= d->N && d->ldpool % 4 == 0,
+                "qea_conv_igemm: pool_y needs a launch qea_conv_igemm_can_pool accepts (tile 24, fp16 operands), ldpool >= N");
+    a.pool_y = d->pool_y;
+    a.ldpool = d->ldpool;
+    a.pool_kw = d->pool_kw;
+    a.pool_amax = d->pool_absmax;
+  }
   if (tile == 4 && !halo_eligible(d)) {
     qea_set_error("qea_conv_igemm: tile 4 (LDS-halo 3x3) needs Cin,N in {32,64}, 3x3 pad 1 stride 1, W %% 32 == 0, no mask / accumulate");
     return QEA_ERR_INVALID;
@@ -1620,6 +1719,17 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20 ? (a.xmax ? 2 : 1) : 0, tag + (tile == 24 && a.xmax ? 5 : 0));
   QEA_CHECK_LAUNCH();
   return QEA_OK;
+}
+
+extern "C" int qea_conv_igemm_can_pool(const qea_conv_desc* d, int32_t kw) {
+  if (!d || d->Cin <= 0 || d->Cin % 32 || d->B <= 0) return 0;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = d->B * d->OH * d->OW;
+  a.N = d->N;
+  a.K = d->KH * d->KW * d->Cin;
+  const int tile = d->tile ? d->tile : pick_tile(d, a);
+  return (tile == 24 && halo_bf3_pool_shape(d, kw)) ? 1 : 0;
 }
 
 extern "C" int qea_conv_igemm_uses_split_bf16(const qea_conv_desc* d) {

@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("ldx", _i32), ("ldy", _i32), ("ldmask", _i32),
         ("relu", _i32), ("accumulate", _i32), ("out_mode", _i32), ("tile", _i32),
         ("x_planes", _fp), ("w_planes", _fp), ("stats", _fp), ("w_frag_planes", _fp), ("x_absmax", _fp), ("y_absmax", _fp),
+        ("pool_y", _fp), ("ldpool", _i32), ("pool_kw", _i32), ("pool_absmax", _fp),
     ]
 
 

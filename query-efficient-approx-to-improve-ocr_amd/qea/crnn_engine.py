@@ -68,17 +68,23 @@ class CRNNEngine:
         for name, cin, cout, relu, pool in CONVS:
             a = torch.empty(B * h * w, cout, device=dev)
             amx["a" + name[-1]] = slot()
-            ops.conv_igemm(cur, P[c + name + ".weight"], a, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1),
-                           ldx=cin, ldy=cout, bias=P[c + name + ".bias"], relu=relu, w_src=("fwd", P[c + name + ".weight"]),
-                           x_amax=amx[cur_name], y_amax=amx["a" + name[-1]])
-            acts["a" + name[-1]] = a
-            dims[name] = (h, w)
-            cur, ccur, cur_name = a, cout, "a" + name[-1]
+            fused_pool = None
             if pool:
                 ph, pw = h // pool[0], w // pool[1]
                 pt = torch.empty(B * ph * pw, cout, device=dev)
                 amx["p" + name[-1]] = slot()
-                ops.maxpool_fwd(a, cout, pt, cout, B, h, w, cout, pool[0], pool[1], amax=amx["p" + name[-1]])
+                # the pool behind relu(conv) leaves with the conv's epilogue where the kernel has the instance (same bits)
+                if FUSE_POOL and pool[0] == 2 and h % 2 == 0 and ops.conv_can_pool(B=B, H=h, W=w, Cin=cin, N=cout, kw=pool[1], ldx=cin, ldy=cout):
+                    fused_pool = (pt, cout, pool[1], amx["p" + name[-1]])
+            ops.conv_igemm(cur, P[c + name + ".weight"], a, B=B, H=h, W=w, Cin=cin, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1),
+                           ldx=cin, ldy=cout, bias=P[c + name + ".bias"], relu=relu, w_src=("fwd", P[c + name + ".weight"]),
+                           x_amax=amx[cur_name], y_amax=amx["a" + name[-1]], pool=fused_pool)
+            acts["a" + name[-1]] = a
+            dims[name] = (h, w)
+            cur, ccur, cur_name = a, cout, "a" + name[-1]
+            if pool:
+                if fused_pool is None:
+                    ops.maxpool_fwd(a, cout, pt, cout, B, h, w, cout, pool[0], pool[1], amax=amx["p" + name[-1]])
                 acts["p" + name[-1]] = pt
                 cur, cur_name = pt, "p" + name[-1]
                 h, w = ph, pw

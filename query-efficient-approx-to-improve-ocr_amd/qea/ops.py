@@ -116,13 +116,15 @@ def transposed(w, R, Cc):
 
 def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(1, 1), ldx, ldy,
                scale=None, bias=None, mask=None, ldmask=0, relu=False, accumulate=False,
-               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None, want_stats=False, x_amax=None, y_amax=None):
+               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None, want_stats=False, x_amax=None, y_amax=None, pool=None):
     """x_planes / w_planes: operands already in the P3 format (a caller that uses a tensor in several launches splits it
     once); when the launch runs on a split-bf16 tile and they are not given, they are made here (one HBM pass each).
     w_src = (kind, weight tensor): `w` is a function of that weight only (itself: kind "fwd"; its cached flip_transposed /
     transposed form: "flipT" / "T"), so its planes are cached with it until the weight changes.
     want_stats: ask for the fused BatchNorm-statistics epilogue; returns (partials [blocks][N][2] fp64, blocks) when the chosen
-    kernel has it, else None (the caller then runs bn_train_stats over y)."""
+    kernel has it, else None (the caller then runs bn_train_stats over y).
+    pool = (pooled, ldpool, kw, amax slot or None): the 2 x kw max-pool of y leaves with the epilogue (same bits as maxpool_fwd on y) —
+    only for a launch conv_can_pool(...) accepted."""
     L = _lib.lib()
     d = _lib.ConvDesc(x=_ptr(x), w=_ptr(w), y=_ptr(y), scale=_ptr(scale), bias=_ptr(bias), mask=_ptr(mask),
                       B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW, N=N, KH=KH, KW=KW, pad_h=pad[0], pad_w=pad[1],
@@ -179,6 +181,9 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
                 d.x_absmax = xmax.data_ptr()
     if y_amax is not None:
         d.y_absmax = y_amax.data_ptr()
+    if pool is not None:
+        d.pool_y, d.ldpool, d.pool_kw = pool[0].data_ptr(), pool[1], pool[2]
+        d.pool_absmax = pool[3].data_ptr() if pool[3] is not None else None
     partials = None
     if want_stats and FUSE_BN_STATS["on"]:
         blocks = L.qea_conv_igemm_stats_blocks(C.byref(d))
@@ -187,6 +192,17 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
             d.stats = partials.data_ptr()
     _lib.check(L.qea_conv_igemm(C.byref(d), _stream()), "qea_conv_igemm")
     return (partials, partials.shape[0] - 256) if partials is not None else None
+
+
+def conv_can_pool(*, B, H, W, Cin, N, kw, ldx, ldy, mask=None):
+    """True when the 3x3 pad-1 layer of this shape can carry the 2 x kw max-pool that follows it in its epilogue (conv_igemm's pool=):
+    the two-way fp16 split is on and the LDS-halo kernel has the instance."""
+    if not (PRESPLIT["on"] and SPLIT_F16["on"] and mfma_mode() == "split_f16") or mask is not None:
+        return False
+    d = _lib.ConvDesc(x=None, w=None, y=None, scale=None, bias=None, mask=None, B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=N, KH=3, KW=3, pad_h=1, pad_w=1,
+                      stride_h=1, stride_w=1, ldx=ldx, ldy=ldy, ldmask=0, relu=0, accumulate=0, out_mode=OUT_NHWC, tile=0, x_planes=None,
+                      w_planes=None, stats=None, w_frag_planes=None)
+    return bool(_lib.lib().qea_conv_igemm_can_pool(C.byref(d), kw))
 
 
 def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride=(1, 1), ldp, ldq,

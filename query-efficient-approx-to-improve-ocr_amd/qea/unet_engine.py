@@ -76,9 +76,12 @@ class UNetEngine:
             coef = torch.empty(4, cout, device=dev)
             ops.bn_eval_coeff(cout, P[blk.key(i, "gamma")], P[blk.key(i, "beta")], Bf[blk.key(i, "rm")], Bf[blk.key(i, "rv")], BN_EPS,
                               None, coef[0], coef[1], coef[2], coef[3])
+            fused_pool = None
+            if pool is not None and FUSE_BN_POOL and ops.conv_can_pool(B=B, H=H, W=W, Cin=cin, N=cout, kw=2, ldx=ldx, ldy=ldo):
+                fused_pool = (pool[0], cout, 2, pool[1])         # ... and so does the 2x2 max-pool behind the block
             ops.conv_igemm(x, w, out, B=B, H=H, W=W, Cin=cin, OH=H, OW=W, N=cout, KH=3, KW=3, pad=(1, 1), ldx=ldx, ldy=ldo,
-                           scale=coef[2], bias=coef[3], relu=True, w_src=("fwd", w), x_amax=x_amax, y_amax=out_amax)
-            return False
+                           scale=coef[2], bias=coef[3], relu=True, w_src=("fwd", w), x_amax=x_amax, y_amax=out_amax, pool=fused_pool)
+            return fused_pool is not None
         y = torch.empty(M, cout, device=dev)
         fused = None
         if cin == 1:

@@ -406,3 +406,36 @@ def test_filter_scale_from_the_whole_parameter_buffer(ratio):
         assert err1 <= 2e-6 * ref1.abs().max().item(), (ratio, err1)
     finally:
         ops.set_mfma_mode(prev)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,B,kw", [(64, 128, 16, 64, 3, 2), (256, 256, 8, 32, 2, 1), (32, 32, 32, 128, 2, 2), (64, 64, 16, 64, 2, 2),
+                                               (256, 256, 4, 16, 5, 2), (128, 128, 8, 32, 3, 2)])
+def test_max_pool_in_the_conv_epilogue_is_bit_identical(Cin, Cout, H, W, B, kw):
+    """qea_conv_desc.pool_y (ABI v7): the 2 x kw max-pool behind relu(conv + bias) written by the LDS-halo kernel's epilogue — y and
+    pooled and both abs-max slots against the same launch without pool_y followed by qea_maxpool_fwd (bit for bit; NaN in the input;
+    the small-image tile with a partly empty last tile: B = 5 images of 4x16)"""
+    from qea import ops
+    prev = ops.set_mfma_mode("split_f16")
+    try:
+        g = torch.Generator().manual_seed(Cin + Cout + H)
+        x = torch.randn(B, H, W, Cin, generator=g).cuda()
+        x[0, 1, 3, 5] = float("nan")
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).cuda()
+        bias = torch.randn(Cout, generator=g).cuda()
+        assert ops.conv_can_pool(B=B, H=H, W=W, Cin=Cin, N=Cout, kw=kw, ldx=Cin, ldy=Cout)
+        y0 = torch.empty(B, H, W, Cout, device="cuda")
+        y1 = torch.empty_like(y0)
+        p0 = torch.empty(B, H // 2, W // kw, Cout, device="cuda")
+        p1 = torch.full_like(p0, -5.0)
+        am = torch.zeros(4, device="cuda")
+        kws = dict(B=B, H=H, W=W, Cin=Cin, OH=H, OW=W, N=Cout, KH=3, KW=3, pad=(1, 1), ldx=Cin, ldy=Cout, bias=bias, relu=True)
+        ops.conv_igemm(x, w, y0, y_amax=am[0:1], **kws)
+        ops.maxpool_fwd(y0, Cout, p0, Cout, B, H, W, Cout, 2, kw, amax=am[1:2])
+        ops.conv_igemm(x, w, y1, y_amax=am[2:3], pool=(p1, Cout, kw, am[3:4]), **kws)
+        torch.cuda.synchronize()
+        assert torch.equal(y0.view(torch.int32), y1.view(torch.int32))
+        assert torch.equal(p0.view(torch.int32), p1.view(torch.int32))
+        assert am[0].item() == am[2].item() and am[1].item() == am[3].item()
+        assert not ops.conv_can_pool(B=B, H=H, W=W, Cin=Cin, N=Cout, kw=3, ldx=Cin, ldy=Cout)
+    finally:
+        ops.set_mfma_mode(prev)

@@ -504,6 +504,15 @@ def test_bn_apply_and_pool_in_one_pass_is_bit_identical():
         torch.cuda.synchronize()
         assert torch.equal(a0.view(torch.int32), a1.view(torch.int32)) and torch.equal(p0.view(torch.int32), p1.view(torch.int32))
         assert am[0].item() == am[2].item() and am[1].item() == am[3].item()
+    res = []
+    for fuse in (True, False):                                   # inference pass: the pool leaves with the conv epilogue (pool_y)
+        unet_engine.FUSE_BN_POOL = fuse
+        try:
+            with torch.no_grad():
+                res.append(_load(UNet(), mo.unet_state_shapes, 1).eval()(H.synth_images(6, 22).cuda()).clone())
+        finally:
+            unet_engine.FUSE_BN_POOL = True
+    assert torch.equal(res[0], res[1])
     for groups in (1, 2):
         res = []
         for fuse in (True, False):
