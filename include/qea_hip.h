@@ -54,7 +54,7 @@ int qea_prof_read_launches(int klass, double* ms, double* flops, int64_t capacit
  * QEA_PROF_TAG_HALO_BF3(CIN, COUT, STATS) — the name rocprofv3 lists it under, so that bench.py's roofline figures of the
  * dominant kernel can be checked against the kernel trace. */
 #define QEA_PROF_TAG_HALO_BF3(cin_chunk, cout_group, stats) (24000 + ((cin_chunk) == 64 ? 1000 : 0) + (cout_group) + ((stats) ? 500 : 0))
-/* (+ 20 * image width for the small-image instantiations, + 5 for the two-way fp16 instantiation: each is its own kernel in a trace) */
+/* (+ 20 * image width for the small-image instantiations, + 5 for the two-way fp16 instantiation: each is its own kernel in a trace); + 2000 * pool_kw for the instantiations with the fused max-pool, ABI v7) */
 int qea_prof_read_tagged(int klass, int32_t tag, double* ms, double* flops, double* bytes, int64_t* launches);
 /* The part of a class's algorithmic flops that ran through the split-bf16 kernels (six bf16 MFMAs per fp32
  * multiply-add): bench.py blends the fp32 and the bf16/6 matrix peaks with it. */

@@ -1715,7 +1715,10 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   // tag = the kernel that ran: QEA_PROF_TAG_CONV(tile, input-channel chunk, output-channel group, fused statistics) for the
   // LDS-halo split kernel (its template instantiation), the tile id otherwise
   // (the small-image instantiations of the halo kernel are their own kernels in a trace: + 20 * image width)
-  const int tag = tile == 24 ? QEA_PROF_TAG_HALO_BF3(d->Cin == 32 ? 32 : 64, d->N > 128 ? 128 : d->N, a.stats != nullptr) + 20 * halo_bf3_small(d) : tile;
+  // (... and so are the instances with the fused max-pool: + 2000 * window width)
+  const int tag = tile == 24 ? QEA_PROF_TAG_HALO_BF3(d->Cin == 32 ? 32 : 64, d->N > 128 ? 128 : d->N, a.stats != nullptr) + 20 * halo_bf3_small(d) +
+                                   (a.pool_y ? 2000 * a.pool_kw : 0)
+                             : tile;
   qea_prof_end(QEA_PROF_CONV_IGEMM, s, 2.0 * a.M * (double)a.N * a.K, abytes, tile >= 20 ? (a.xmax ? 2 : 1) : 0, tag + (tile == 24 && a.xmax ? 5 : 0));
   QEA_CHECK_LAUNCH();
   return QEA_OK;

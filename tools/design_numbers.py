@@ -7,7 +7,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda *a: os.path.join(ROOT, *a)
-DOM = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 2>"
+DOM = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 2, 0>"
 WG = "wgrad_halo9_bf3_kernel<32, 64, 64, 2>"
 BEGIN, END = "<!-- numbers:begin -->", "<!-- numbers:end -->"
 
@@ -53,7 +53,7 @@ single-stream trace {total / 13e6:.1f} ms per step.
     s = s[:a] + nums + s[b:]
     open(P("DESIGN.md"), "w").write(s)
     s = open(P("profiles", "README.md")).read()
-    s = re.sub(r"CROSSCHECK[^|]*\|", f"`{DOM}` {tr[0]} calls (13 steps × 26), average {tr[1]:.1f} µs in the trace against `roofline.avg_launch_us` = "
+    s = re.sub(r"CROSSCHECK[^|]*\|", f"`{DOM}` {tr[0]} calls (13 steps × {tr[0] // 13}), average {tr[1]:.1f} µs in the trace against `roofline.avg_launch_us` = "
                f"{u['roofline']['avg_launch_us']:.1f} µs from bench.py's HIP events in the same run |", s, count=1)
     open(P("profiles", "README.md"), "w").write(s)
     print("ok", d["value"], r["frac"], tr, u["roofline"]["avg_launch_us"])
