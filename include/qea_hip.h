@@ -150,6 +150,16 @@ typedef struct qea_conv_desc {
   int32_t ldpool;
   int32_t pool_kw;
   float* pool_absmax;
+  /* ABI v7: the launch is an INPUT GRADIENT (3x3 dgrad on the LDS-halo kernel, fp16 operands) whose output da feeds the backward of a
+   * train-mode BatchNorm(+ReLU) (models/model_unet.py:78-109 under autograd).  bst_y non-NULL (with `stats`): instead of the forward
+   * statistics, `stats` receives per partial block the fp64 sums of dz = da * [bst_scale * bst_y + bst_shift > 0] and of
+   * dz * (bst_y - mean) * invstd, mean / invstd = bst_stat64[0..N) / [N..2N) — the reductions qea_bn_bwd otherwise makes in a pass of
+   * its own over da and bst_y; qea_bn_bwd_from_partials consumes them.  Block count: qea_conv_igemm_stats_blocks. */
+  const float* bst_y;
+  int32_t ldbst;
+  const double* bst_stat64;
+  const float* bst_scale;
+  const float* bst_shift;
 } qea_conv_desc;
 
 int qea_conv_igemm(const qea_conv_desc* d, void* stream);
@@ -268,6 +278,14 @@ int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const
                const float* relu_shift, const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* mean, const float* invstd, const double* stat64,
                int32_t training, float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy,
                int32_t lddy, void* workspace, size_t workspace_bytes, float* absmax_out, void* stream);
+/* ABI v7 (additive).  qea_bn_bwd with the two per-channel reductions taken from `partials` [blocks (+ 256 scratch rows)][C][2] fp64, as
+ * written by the producing input-gradient launch (qea_conv_desc.bst_y), instead of a pass over da and y: finalize + the elementwise
+ * pass only.  stat64 and relu_scale / relu_shift are required (what the producer used); workspace: 3 * C doubles. */
+int qea_bn_bwd_from_partials(const double* partials, int32_t blocks, const float* da, int32_t ldda, const float* relu_scale,
+                             const float* relu_shift, const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma,
+                             const float* mean, const float* invstd, const double* stat64, int32_t training, float* dgamma, float* dbeta,
+                             int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace, size_t workspace_bytes,
+                             float* absmax_out, void* stream);
 /* out[c] (+)= sum_m x[m][c]  — conv / linear / LSTM bias gradients */
 int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, float* out, int32_t accumulate, void* workspace,
                size_t workspace_bytes, void* stream);

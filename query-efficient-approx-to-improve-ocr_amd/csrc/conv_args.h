@@ -28,6 +28,13 @@ struct ConvArgs {
   float* pool_y;
   int ldpool, pool_kw;
   float* pool_amax;
+  // BatchNorm-backward partial sums of the stored tensor (LDS-halo kernel only; the partials go to `stats`): the BatchNorm's input
+  // (pre-BN conv output), its pixel stride, [2][N] fp64 mean / invstd, the forward's scale / shift (ReLU mask)
+  const float* bst_y;
+  int ldbst;
+  const double* bst64;
+  const float* bst_scale;
+  const float* bst_shift;
 };
 
 // Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,

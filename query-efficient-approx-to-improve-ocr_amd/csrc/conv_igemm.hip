@@ -985,13 +985,18 @@ constexpr int halo_bf3_wgs(int cin, int cout, int npl) { return (npl == 2 && cou
 // PKW != 0 (round 3): the max-pool that follows the layer leaves with the epilogue — window 2 x PKW over the STORED values (after scale /
 // bias / ReLU), scan order and NaN rule of maxpool_fwd_kernel, written to `pooled` (pixel stride ldp) next to the full-resolution
 // output; a row pair and, for PKW = 2, a pixel pair sit in one lane's accumulators (needs MI even).  No mask, no statistics.
-template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3, int PKW = 0>
+// BST (round 3): the launch is an INPUT GRADIENT whose output da feeds a train-mode BatchNorm(+ReLU) backward: the epilogue also leaves,
+// per (pixel tile, wave row) and output column, the fp64 partial sums of dz = da * [scale * yref + shift > 0] and of dz * (yref - mean) *
+// invstd — what colreduce_kernel<1> computes in a pass of its own over da and yref (the partials' layout is the STATS one).
+template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3, int PKW = 0, bool BST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wgs(CIN, COUT, NPL), halo_bf3_wgs(CIN, COUT, NPL)))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
                                                                int Ntot, const float* __restrict__ mask, int ldmask, int total,
                                                                const float* __restrict__ xmax, float* __restrict__ yamax,
-                                                               float* __restrict__ pooled, int ldp, float* __restrict__ pamax) {
+                                                               float* __restrict__ pooled, int ldp, float* __restrict__ pamax,
+                                                               const float* __restrict__ yref, int ldyref, const double* __restrict__ bst64,
+                                                               const float* __restrict__ bsc, const float* __restrict__ bsh) {
   constexpr bool F16 = NPL == 2;
   typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
   constexpr bool SMALL = IMW != 0;
@@ -1006,6 +1011,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
   constexpr int PLANE = HP * CIN;                       // bf16 elements per plane
   static_assert(MI >= 1 && TH % WM == 0, "tile rows must split over the waves");
   static_assert(PKW == 0 || (MI % 2 == 0 && !STATS && (PKW == 1 || PKW == 2)), "fused pooling: row pairs inside one wave, no statistics");
+  static_assert(!BST || (!STATS && PKW == 0), "BatchNorm-backward sums: their own instances");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* As = reinterpret_cast<__bf16*>(smem);         // [NPL][HP][CIN] (16-bit elements: bf16, or fp16 when NPL == 2)
   float sx = 1.f, inv_x = 1.f, inv_w = 1.f;
@@ -1214,6 +1220,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
     const int fr = lane & 31, fh = lane >> 5;
     const int n = cur.nb * COUT + wn * 32 + fr;
     const float esc = scale ? scale[n] : 1.f, ebi = bias ? bias[n] : 0.f;
+    float msc = 0.f, msh = 0.f;
+    double bmu = 0.0, bis = 0.0;
+    if constexpr (BST) {
+      msc = bsc[n];
+      msh = bsh[n];
+      bmu = bst64[n];
+      bis = bst64[Ntot + n];
+    }
     double st0 = 0.0, st1 = 0.0;
     float am = 0.f;
     if constexpr (PKW != 0) {
@@ -1301,11 +1315,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
           st0 += (double)v;
           st1 += (double)v * (double)v;
         }
+        if constexpr (BST) {                            // (the very mask and the very terms of colreduce_kernel<1>)
+          const float yv = yref[prow * ldyref + n];
+          const float dz = __fmaf_rn(yv, msc, msh) > 0.f ? v : 0.f;
+          st0 += (double)dz;
+          st1 += (double)dz * (((double)yv - bmu) * bis);
+        }
       }
     }
     }
     qea_amax_commit(am, yamax);
-    if (STATS) {                                        // one partial per (pixel tile, wave row): [blocks][Ntot][2]
+    if (STATS || BST) {                                        // one partial per (pixel tile, wave row): [blocks][Ntot][2]
       const double sa = st0 + __shfl_xor(st0, 32, 64);
       const double sc = st1 + __shfl_xor(st1, 32, 64);
       if (fh == 0) {
@@ -1384,10 +1404,10 @@ __global__ void pack_frag_planes_f16_kernel(const float* __restrict__ w, _Float1
   for (int p = 0; p < 2; ++p) *reinterpret_cast<f16x8*>(dst + ((((size_t)gst * 2 + p) * WNr + nj) * 64 + lane) * 8) = pl[p];
 }
 
-template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3, int PKW = 0>
+template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3, int PKW = 0, bool BST = false>
 int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
   constexpr size_t lds = IMW ? (size_t)NPL * (TH + 1) * (32 / IMW) * (IMW + 2) * CIN * 2 : (size_t)NPL * (TH + 2) * 34 * CIN * 2;
-  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS, IMW, NPL, PKW>;
+  auto kern = conv3x3_halo_bf3_kernel<CIN, COUT, TH, STATS, IMW, NPL, PKW, BST>;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr_rc != (int)hipSuccess) {
     qea_set_error("qea_conv_igemm(halo bf3): cannot reserve %zu bytes of LDS: %s", (size_t)lds, hipGetErrorString((hipError_t)attr_rc));
@@ -1411,7 +1431,8 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
   // (re-measured with the fp16 split and three workgroups per CU: persistent 0.779 / 1.431 ms against 0.750 / 1.331 one item each)
   const unsigned grid = (total > resident && COUT > 32) ? (unsigned)resident : (unsigned)total;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a.x, (const __bf16*)a.wp, a.y, a.B, a.H, a.W, a.ldx, a.ldy,
-                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total, a.xmax, a.yamax, a.pool_y, a.ldpool, a.pool_amax);
+                     a.scale, a.bias, a.relu, a.stats, a.Cin / CIN, a.N, a.mask, a.ldmask, (int)total, a.xmax, a.yamax, a.pool_y, a.ldpool, a.pool_amax,
+                     a.bst_y, a.ldbst, a.bst64, a.bst_scale, a.bst_shift);
   return QEA_OK;
 }
 
@@ -1425,6 +1446,8 @@ int launch_halo_bf3_pool(const ConvArgs& a, hipStream_t s) {
 
 template <int CIN, int COUT, int TH, int IMW = 0>
 int launch_halo_bf3(const ConvArgs& a, hipStream_t s) {
+  if (a.xmax && a.bst_y)                                   // ... with the BatchNorm-backward sums of the tensor it writes (fp16 form only)
+    return launch_halo_bf3_<CIN, COUT, TH, false, IMW, 2, 0, true>(a, s);
   if (a.xmax)                                              // two-way fp16 split: the caller gave the input's abs-max and fp16 filter planes
     return a.stats ? launch_halo_bf3_<CIN, COUT, TH, true, IMW, 2>(a, s) : launch_halo_bf3_<CIN, COUT, TH, false, IMW, 2>(a, s);
   return a.stats ? launch_halo_bf3_<CIN, COUT, TH, true, IMW>(a, s) : launch_halo_bf3_<CIN, COUT, TH, false, IMW>(a, s);
@@ -1635,6 +1658,10 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
   a.pool_y = nullptr;
   a.ldpool = a.pool_kw = 0;
   a.pool_amax = nullptr;
+  a.bst_y = nullptr;
+  a.ldbst = 0;
+  a.bst64 = nullptr;
+  a.bst_scale = a.bst_shift = nullptr;
 
   hipStream_t s = (hipStream_t)stream;
   int tile = resolve_tile(d, a);
@@ -1666,6 +1693,15 @@ extern "C" int qea_conv_igemm(const qea_conv_desc* d, void* stream) {
     const int blocks = stats_blocks_for(d, a, tile, wp3);
     QEA_REQUIRE(blocks > 0, "qea_conv_igemm: this launch cannot produce fused statistics (ask qea_conv_igemm_stats_blocks first)");
     a.stats = d->stats;
+  }
+  if (d->bst_y) {                                          // BatchNorm-backward sums instead of the forward statistics: LDS-halo kernel, fp16 form
+    QEA_REQUIRE(d->stats && tile == 24 && d->x_absmax && !d->pool_y && d->bst_stat64 && d->bst_scale && d->bst_shift && d->ldbst >= d->N,
+                "qea_conv_igemm: bst_y needs stats (the partials), tile 24 with fp16 operands, bst_stat64 / bst_scale / bst_shift, ldbst >= N");
+    a.bst_y = d->bst_y;
+    a.ldbst = d->ldbst;
+    a.bst64 = d->bst_stat64;
+    a.bst_scale = d->bst_scale;
+    a.bst_shift = d->bst_shift;
   }
   if (tile == 24 && (!halo_bf3_eligible(d) || !d->w_frag_planes)) {
     qea_set_error("qea_conv_igemm: tile 24 needs Cin = 32 or 64k <= 512, N in {32,64,128k}, 3x3 pad 1 stride 1, W %% 32 == 0 (or 4x16 / 2x8 images with Cin = 64k, N = 128k), no accumulate, and w_frag_planes");

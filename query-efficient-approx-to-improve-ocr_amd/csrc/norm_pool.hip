@@ -600,6 +600,42 @@ extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t
   return QEA_OK;
 }
 
+extern "C" int qea_bn_bwd_from_partials(const double* partials, int32_t blocks, const float* da, int32_t ldda, const float* relu_scale,
+                                        const float* relu_shift, const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma,
+                                        const float* mean, const float* invstd, const double* stat64, int32_t training, float* dgamma,
+                                        float* dbeta, int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace,
+                                        size_t workspace_bytes, float* absmax_out, void* stream) {
+  QEA_REQUIRE(partials && blocks > 0 && da && y && mean && invstd && dy && stat64 && relu_scale && relu_shift && M > 0 && C > 0 && C % 4 == 0,
+              "qea_bn_bwd_from_partials: null pointer / bad size (stat64 and relu_scale / relu_shift are required)");
+  QEA_REQUIRE(ldda % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0, "qea_bn_bwd_from_partials: strides must be multiples of 4");
+  QEA_REQUIRE(workspace && workspace_bytes >= (size_t)3 * C * sizeof(double), "qea_bn_bwd_from_partials: workspace too small (3 * C doubles)");
+  const ColGeom g = col_geom(M, C);
+  hipStream_t s = (hipStream_t)stream;
+  double* k0 = (double*)workspace;
+  double* k1 = k0 + C;
+  double* k2 = k1 + C;
+  const double* src = partials;
+  int nblk = blocks;
+  if (blocks > QEA_BN_PARTIAL_SCRATCH_ROWS * 2) {          // two stages, as qea_bn_train_stats_from_partials
+    const int per = qea_cdiv(blocks, QEA_BN_PARTIAL_SCRATCH_ROWS);
+    nblk = qea_cdiv(blocks, per);
+    double* scratch = const_cast<double*>(partials) + (size_t)blocks * C * 2;
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3(nblk), dim3(256), (size_t)256 * 2 * sizeof(double), s, partials, blocks, C, per, scratch);
+    src = scratch;
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, src, nblk, C, (long long)M, gamma, mean, invstd, stat64,
+                     training, dgamma, dbeta, accumulate_param_grads, k0, k1, k2);
+  long long agrid = (M + (long long)g.rt * 8 - 1) / ((long long)g.rt * 8);
+  if (agrid > 4096) agrid = 4096;
+  if (agrid < 1) agrid = 1;
+  const int arows = (int)((M + agrid - 1) / agrid);
+  agrid = (M + arows - 1) / arows;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)agrid), dim3(RED_THREADS), 0, s, da, ldda, (const float*)nullptr, 0, y, ldy, dy, lddy,
+                     (long long)M, C, relu_scale, relu_shift, (const double*)k0, (const double*)k1, (const double*)k2, arows, g.rt, absmax_out);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
 extern "C" int qea_colsum(const float* x, int32_t ldx, int64_t M, int32_t C, float* out, int32_t accumulate, void* workspace,
                           size_t workspace_bytes, void* stream) {
   QEA_REQUIRE(x && out, "qea_colsum: null pointer");

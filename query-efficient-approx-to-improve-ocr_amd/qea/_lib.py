@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("relu", _i32), ("accumulate", _i32), ("out_mode", _i32), ("tile", _i32),
         ("x_planes", _fp), ("w_planes", _fp), ("stats", _fp), ("w_frag_planes", _fp), ("x_absmax", _fp), ("y_absmax", _fp),
         ("pool_y", _fp), ("ldpool", _i32), ("pool_kw", _i32), ("pool_absmax", _fp),
+        ("bst_y", _fp), ("ldbst", _i32), ("bst_stat64", _fp), ("bst_scale", _fp), ("bst_shift", _fp),
     ]
 
 

@@ -116,7 +116,8 @@ def transposed(w, R, Cc):
 
 def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(1, 1), ldx, ldy,
                scale=None, bias=None, mask=None, ldmask=0, relu=False, accumulate=False,
-               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None, want_stats=False, x_amax=None, y_amax=None, pool=None):
+               out_mode=OUT_NHWC, tile=0, x_planes=None, w_planes=None, w_src=None, want_stats=False, x_amax=None, y_amax=None, pool=None,
+               bwd_stats=None):
     """x_planes / w_planes: operands already in the P3 format (a caller that uses a tensor in several launches splits it
     once); when the launch runs on a split-bf16 tile and they are not given, they are made here (one HBM pass each).
     w_src = (kind, weight tensor): `w` is a function of that weight only (itself: kind "fwd"; its cached flip_transposed /
@@ -124,7 +125,10 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
     want_stats: ask for the fused BatchNorm-statistics epilogue; returns (partials [blocks][N][2] fp64, blocks) when the chosen
     kernel has it, else None (the caller then runs bn_train_stats over y).
     pool = (pooled, ldpool, kw, amax slot or None): the 2 x kw max-pool of y leaves with the epilogue (same bits as maxpool_fwd on y) —
-    only for a launch conv_can_pool(...) accepted."""
+    only for a launch conv_can_pool(...) accepted.
+    bwd_stats = (y_ref, ld, stat64 [2][N], scale, shift): y (this launch's output) is the gradient entering a train-mode BatchNorm+ReLU
+    whose input was y_ref: the epilogue also leaves the two reductions of that BatchNorm's backward; returns (partials, blocks) for
+    bn_bwd(partials=...), or None when this launch has no such epilogue (the caller's bn_bwd then makes its own pass)."""
     L = _lib.lib()
     d = _lib.ConvDesc(x=_ptr(x), w=_ptr(w), y=_ptr(y), scale=_ptr(scale), bias=_ptr(bias), mask=_ptr(mask),
                       B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW, N=N, KH=KH, KW=KW, pad_h=pad[0], pad_w=pad[1],
@@ -185,7 +189,14 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
         d.pool_y, d.ldpool, d.pool_kw = pool[0].data_ptr(), pool[1], pool[2]
         d.pool_absmax = pool[3].data_ptr() if pool[3] is not None else None
     partials = None
-    if want_stats and FUSE_BN_STATS["on"]:
+    if bwd_stats is not None and wants == 1 and d.x_absmax and FUSE_BN_STATS["on"]:
+        blocks = L.qea_conv_igemm_stats_blocks(C.byref(d))
+        if blocks > 0:
+            partials = torch.empty(blocks + 256, N, 2, dtype=torch.float64, device=x.device)   # + QEA_BN_PARTIAL_SCRATCH_ROWS
+            d.stats = partials.data_ptr()
+            d.bst_y, d.ldbst, d.bst_stat64 = bwd_stats[0].data_ptr(), bwd_stats[1], bwd_stats[2].data_ptr()
+            d.bst_scale, d.bst_shift = bwd_stats[3].data_ptr(), bwd_stats[4].data_ptr()
+    elif want_stats and FUSE_BN_STATS["on"]:
         blocks = L.qea_conv_igemm_stats_blocks(C.byref(d))
         if blocks > 0:
             partials = torch.empty(blocks + 256, N, 2, dtype=torch.float64, device=x.device)   # + QEA_BN_PARTIAL_SCRATCH_ROWS
@@ -418,9 +429,16 @@ def bn_apply(y, ldy, a, lda, M, C_, scale, shift, relu=True, amax=None):
 
 
 def bn_bwd(da, ldda, a, lda, y, ldy, M, C_, gamma, mean, invstd, training, dgamma, dbeta, dy, lddy, accumulate=False, stat64=None,
-           relu_scale=None, relu_shift=None, amax=None):
-    """ReLU mask: pass the activation `a`, or a=None with the forward's scale/shift (mask recomputed from y, one tensor read less)."""
+           relu_scale=None, relu_shift=None, amax=None, partials=None):
+    """ReLU mask: pass the activation `a`, or a=None with the forward's scale/shift (mask recomputed from y, one tensor read less).
+    partials = (tensor, blocks) from conv_igemm(bwd_stats=...): the reductions came with da's producer (no pass over da and y here)."""
     wp, wn = _colws(M, C_, da.device)
+    if partials is not None:
+        _lib.check(_lib.lib().qea_bn_bwd_from_partials(partials[0].data_ptr(), partials[1], _ptr(da), ldda, _ptr(relu_scale), _ptr(relu_shift), _ptr(y),
+                                                       ldy, M, C_, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(stat64), int(training), _ptr(dgamma),
+                                                       _ptr(dbeta), int(accumulate), _ptr(dy), lddy, wp, wn, _ptr(amax), _stream()),
+                   "qea_bn_bwd_from_partials")
+        return
     _lib.check(_lib.lib().qea_bn_bwd(_ptr(da), ldda, _ptr(a), lda, _ptr(relu_scale), _ptr(relu_shift), _ptr(y), ldy, M, C_, _ptr(gamma), _ptr(mean),
                                      _ptr(invstd), _ptr(stat64), int(training), _ptr(dgamma), _ptr(dbeta), int(accumulate),
                                      _ptr(dy), lddy, wp, wn, _ptr(amax), _stream()), "qea_bn_bwd")

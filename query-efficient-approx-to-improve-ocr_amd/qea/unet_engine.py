@@ -20,6 +20,7 @@ from .params import ensure_flat
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 FUSE_EVAL_BN = True   # tests flip this to compare the fused inference epilogue with the two-pass form
+FUSE_BN_BWD_SUMS = True   # tests flip this: BatchNorm1's backward reductions from the producing dgrad's epilogue (qea_conv_desc.bst_y)
 FUSE_BN_POOL = True   # tests flip this: the encoder's BatchNorm apply + ReLU and its 2x2 max-pool in one pass (qea_bn_apply_pool)
 
 
@@ -215,11 +216,12 @@ class UNetEngine:
         pool = ops.amax_pool(dev)
         slot = (lambda: pool.slot()) if pool is not None else (lambda: None)
 
-        def bn_bwd(da, ldda, y, coef, st, i, dy, M, cout, blk, amax=None):
+        def bn_bwd(da, ldda, y, coef, st, i, dy, M, cout, blk, amax=None, partials=None):
             """BatchNorm(+ReLU) backward of conv i of a block; per statistics group when the forward ran with bn_groups"""
             if coef.dim() == 2:
                 ops.bn_bwd(da, ldda, None, 0, y, cout, M, cout, P[blk.key(i, "gamma")], coef[0], coef[1], training, G[blk.key(i, "gamma")],
-                           G[blk.key(i, "beta")], dy, cout, accumulate=True, stat64=st, relu_scale=coef[2], relu_shift=coef[3], amax=amax)
+                           G[blk.key(i, "beta")], dy, cout, accumulate=True, stat64=st, relu_scale=coef[2], relu_shift=coef[3], amax=amax,
+                           partials=partials)
                 return
             Mg = M // NG
             for g in range(NG):
@@ -245,10 +247,15 @@ class UNetEngine:
                                             pad=(1, 1), ldp=cout, ldq=cout, accumulate=True, p_amax=dy2_amax, q_amax=s.get("a1_amax")), dy2)
             w2t = ops.flip_transposed(w2, cout, cout, 3, 3)
             da1 = torch.empty(M, cout, device=dev)
-            ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout,
-                           w_src=("flipT", w2), x_amax=dy2_amax)
+            # the two reductions of BatchNorm1's backward come with da1 from the dgrad's epilogue (FUSE_BN_BWD_SUMS; train mode, one
+            # statistics group, fp16 form) instead of a pass of their own over da1 and y1
+            bst = None
+            if FUSE_BN_BWD_SUMS and training and s["coef1"].dim() == 2 and s["st1"] is not None:
+                bst = (s["y1"], cout, s["st1"], s["coef1"][2], s["coef1"][3])
+            part = ops.conv_igemm(dy2, w2t, da1, B=B, H=h, W=w, Cin=cout, OH=h, OW=w, N=cout, KH=3, KW=3, pad=(1, 1), ldx=cout, ldy=cout,
+                                  w_src=("flipT", w2), x_amax=dy2_amax, bwd_stats=bst)
             dy1 = torch.empty(M, cout, device=dev)       # (dy2 may still be read by its wgrad on the side stream)
-            bn_bwd(da1, cout, s["y1"], s["coef1"], s["st1"], 1, dy1, M, cout, blk, dy1_amax)
+            bn_bwd(da1, cout, s["y1"], s["coef1"], s["st1"], 1, dy1, M, cout, blk, dy1_amax, partials=part if bst is not None else None)
             if cin == 1:
                 side.run(lambda: ops.conv_c1_wgrad(s["xin"], dy1, cout, G[blk.key(1, "w")], None, B, h, w, cout, accumulate=True), dy1)
                 return None

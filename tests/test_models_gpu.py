@@ -565,3 +565,61 @@ def test_crnn_fused_pools_are_bit_identical():
             finally:
                 crnn_engine.FUSE_POOL = True
         assert all(torch.equal(u, v) for u, v in zip(*res))
+
+
+def test_bn_backward_sums_from_the_dgrad_epilogue():
+    """qea_conv_desc.bst_y (ABI v7): the two per-channel reductions of BatchNorm1's backward (sum dz, sum dz * xhat with the ReLU mask
+    recomputed from the pre-BN tensor; models/model_unet.py:78-109 under autograd) written as fp64 partials by the epilogue of the 3x3
+    dgrad that produces da, consumed by qea_bn_bwd_from_partials — against the separate pass (colreduce) through the whole UNet
+    backward: every gradient to fp64-summation-order noise, and the fused launch really ran (profiling tag of the BST instances is the
+    plain one, so count launches of the reduction kernel instead: fewer colreduce passes is checked through the result only)."""
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea import ops, unet_engine
+    res, fused_calls = [], []
+    real_bn_bwd = ops.bn_bwd
+
+    def counting_bn_bwd(*a, **k):
+        fused_calls[-1] += k.get("partials") is not None
+        return real_bn_bwd(*a, **k)
+    ops.bn_bwd = counting_bn_bwd
+    try:
+        for fuse in (True, False):
+            unet_engine.FUSE_BN_BWD_SUMS = fuse
+            fused_calls.append(0)
+            net = _load(UNet(), mo.unet_state_shapes, 1).train()
+            x = H.synth_images(6, 31).cuda()
+            out = net(x)
+            (out * torch.linspace(0.5, 1.5, out.numel(), device="cuda").view_as(out)).sum().backward()
+            res.append([p.grad.clone() for p in net.parameters()])
+    finally:
+        ops.bn_bwd = real_bn_bwd
+        unet_engine.FUSE_BN_BWD_SUMS = True
+    assert fused_calls == [9, 0], fused_calls          # BatchNorm1 of the nine blocks took its sums from the dgrad epilogue
+    worst = 0.0
+    for u, v in zip(*res):
+        den = v.double().norm().item()
+        if den > 0:
+            worst = max(worst, (u.double() - v.double()).norm().item() / den)
+    assert worst <= 2e-6, worst                        # (fp64 partials in another grouping: equal or a few last-bit flips)
+    # kernel level: the partials of one launch against fp64 sums of the definition
+    g = torch.Generator().manual_seed(8)
+    B, Hh, Ww, Cc = 3, 8, 32, 128
+    dy = torch.randn(B, Hh, Ww, Cc, generator=g).cuda()
+    w = (torch.randn(Cc, 3, 3, Cc, generator=g) / (9 * Cc) ** 0.5).cuda()
+    yref = torch.randn(B, Hh, Ww, Cc, generator=g).cuda()
+    sc, sh = (torch.rand(Cc, generator=g) + 0.5).cuda(), torch.randn(Cc, generator=g).cuda()
+    st = torch.stack([torch.randn(Cc, generator=g).double(), (torch.rand(Cc, generator=g) + 0.5).double()]).cuda()
+    da = torch.empty(B, Hh, Ww, Cc, device="cuda")
+    prev = ops.set_mfma_mode("split_f16")
+    try:
+        got = ops.conv_igemm(dy, w, da, B=B, H=Hh, W=Ww, Cin=Cc, OH=Hh, OW=Ww, N=Cc, KH=3, KW=3, pad=(1, 1), ldx=Cc, ldy=Cc,
+                             bwd_stats=(yref, Cc, st, sc, sh))
+    finally:
+        ops.set_mfma_mode(prev)
+    assert got is not None
+    part = got[0][:got[1]].sum(0).cpu()                                   # [C][2]
+    dz = (da.double() * (torch.addcmul(sh, yref, sc) > 0)).reshape(-1, Cc)
+    xh = ((yref.double() - st[0]) * st[1]).reshape(-1, Cc)
+    assert (part[:, 0] - dz.sum(0).cpu()).abs().max().item() <= 1e-9 * dz.abs().sum(0).max().item()
+    assert (part[:, 1] - (dz * xh).sum(0).cpu()).abs().max().item() <= 1e-9 * (dz * xh).abs().sum(0).max().item()
