@@ -150,7 +150,7 @@ def cpu_baseline():
             "b128": b128, "b32": b32, "host": host}
 
 
-DOMINANT_KERNEL = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 2, 0>"
+DOMINANT_KERNEL = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 2, 0, false>"
 DOMINANT_KERNEL_BF16 = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 3>"
 
 
