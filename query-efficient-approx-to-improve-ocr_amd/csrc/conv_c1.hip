@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd4_pool_kernel(const float* __r
       for (int k = 0; k < 4; ++k) pm = qea_amax_acc(pm, m[k]);
     }
   }
-  qea_amax_commit(pm, amax_p);
+  qea_amax_commit_block(pm, amax_p);
 }
 
 // dW[co][tap] = sum_p dy[p][co] * x[p + tap]; db[co] = sum_p dy[p][co].

@@ -1127,6 +1127,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
   gather(cur, 0, threadIdx.x);
   load_b(cur.nb, 0, 0, threadIdx.x);
   bool first = true;
+  // abs-max of everything this workgroup stores, committed ONCE after its last item: a commit per item put an L2 round trip (the
+  // gate's load of the shared slot) at the end of every tile and 262 k same-address accesses into one launch of the 32x128 level
+  float am = 0.f, pm = 0.f;
   while (true) {
     const int nvb = vb + gridDim.x;
     const bool has_next = nvb < total;
@@ -1229,9 +1232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
       bis = bst64[Ntot + n];
     }
     double st0 = 0.0, st1 = 0.0;
-    float am = 0.f;
     if constexpr (PKW != 0) {
-      float pm = 0.f;
 #pragma unroll
       for (int i = 0; i < MI; i += 2) {
         float vv[2][16];
@@ -1285,7 +1286,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
           pm = qea_amax_acc(pm, m);
         }
       }
-      qea_amax_commit(pm, pamax);
     } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -1324,7 +1324,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
       }
     }
     }
-    qea_amax_commit(am, yamax);
     if (STATS || BST) {                                        // one partial per (pixel tile, wave row): [blocks][Ntot][2]
       const double sa = st0 + __shfl_xor(st0, 32, 64);
       const double sc = st1 + __shfl_xor(st1, 32, 64);
@@ -1338,6 +1337,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
     cur = nxt;
     vb = nvb;
   }
+  qea_amax_commit(am, yamax);
+  if constexpr (PKW != 0) qea_amax_commit(pm, pamax);
 }
 
 // w [N][9][Cin] fp32 -> fragment-ordered planes [chunk][step = tap*KS + cs][plane][nj][lane][8 bf16], chunk width CW (32 or 64

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm1x1_wgs
   gather(cur_tm, 0);
   load_b(cur_nb, 0, 0);
   bool first = true;
+  float am = 0.f;
   while (true) {
     const int nvb = vb + gridDim.x;
     const bool has_next = nvb < total;
@@ -177,7 +178,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm1x1_wgs
     }
 
     // ---- epilogue: v = acc / (s_x s_w) + bias; ReLU; store.  Accumulator row = (r & 3) + 8 (r >> 2) + 4 fh of block i, column fr.
-    float am = 0.f;
     const int* rp = rowpix + par * BM;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -205,13 +205,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm1x1_wgs
         }
       }
     }
-    qea_amax_commit(am, p.yamax);
     if (!has_next) break;
     cur_nb = nxt_nb;
     cur_tm = nxt_tm;
     vb = nvb;
     par ^= 1;
   }
+  qea_amax_commit(am, p.yamax);                            // once per workgroup, after its last item (not an L2 round trip per item)
 }
 
 template <int CIN, int WM, int NJ>

@@ -371,8 +371,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
       m = (a <= 3.4028234663852886e38f && a > m) ? a : m;      // the comparison is false for NaN; inf is excluded by the bound
     }
   }
-  m = qea_wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, __float_as_uint(m));
+  qea_amax_commit_block(m, reinterpret_cast<float*>(out));   // one gated access per workgroup
 }
 
 extern "C" int qea_absmax(const float* x, int32_t ld, int64_t M, int32_t C, float* out, void* stream) {

@@ -229,7 +229,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, int ldy, float* __r
     }
     *reinterpret_cast<f32x4*>(a + r * lda + ct * 4) = o;
   }
-  qea_amax_commit(am, amax);
+  qea_amax_commit_block(am, amax);
 }
 
 __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ a, int lda,
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* 
     const f32x4 aa = a ? *reinterpret_cast<const f32x4*>(a + r * lda + ct * 4) : zero;
     one(r, dza, ya, aa);
   }
-  qea_amax_commit(am, amax);
+  qea_amax_commit_block(am, amax);
 }
 
 // max-pool with window == stride (2x2 or 2x1), PyTorch tie rule: first maximum in (kh,kw) scan order
@@ -324,7 +324,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* 
 #pragma unroll
     for (int k = 0; k < 4; ++k) am = qea_amax_acc(am, m[k]);
   }
-  qea_amax_commit(am, amax);
+  qea_amax_commit_block(am, amax);
 }
 
 // BatchNorm apply (+ReLU) AND the max-pool that follows it, one pass (model_unet.py:51-59: enc -> pool): a thread owns
@@ -363,8 +363,8 @@ __global__ void bn_apply_pool_kernel(const float* __restrict__ y, int ldy, float
 #pragma unroll
     for (int k = 0; k < 4; ++k) pm = qea_amax_acc(pm, m[k]);
   }
-  qea_amax_commit(am, amax_a);
-  qea_amax_commit(pm, amax_p);
+  qea_amax_commit_block(am, amax_a);
+  qea_amax_commit_block(pm, amax_p);
 }
 
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, float* __restrict__ dx,
@@ -410,7 +410,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const f
         for (int k = 0; k < 4; ++k) am = qea_amax_acc(am, o[k]);
       }
   }
-  qea_amax_commit(am, amax);
+  qea_amax_commit_block(am, amax);
 }
 
 // out[c][r] = in[r][c]  (32x32 LDS tiles)

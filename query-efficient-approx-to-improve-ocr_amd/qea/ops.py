@@ -291,8 +291,8 @@ def filter_absmax(w_src, w, ld, M, Cc):
     filter and derived form): any bound >= the filter's own max is a valid scale source, and the fp16 pair keeps all 22 bits of
     every element down to 2^-17 of the bound, far below the spread between a model's layers."""
     from .params import flat_state_of
-    fs = flat_state_of(w_src[1]) if w_src is not None else None
-    if fs is None or fs.total % 4:
+    fs = flat_state_of(w_src[1], check=False) if w_src is not None else None
+    if fs is None or fs.total % 4 or fs.data.data_ptr() > w_src[1].data_ptr() or w_src[1].data_ptr() >= fs.data.data_ptr() + 4 * fs.total:
         return absmax(w, ld, M, Cc)
     return weight_cached("flat_absmax", fs.data, lambda: absmax(fs.data, fs.total, 1, fs.total))
 
