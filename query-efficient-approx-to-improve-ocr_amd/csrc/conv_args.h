@@ -107,7 +107,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const f32x16 (&
       }
     }
   }
-  qea_amax_commit(am, p.yamax);                            // (every lane of the workgroup runs the epilogue to its end)
+  qea_amax_commit_block(am, p.yamax);                      // (every lane of the workgroup runs the epilogue to its end: one gated access per workgroup)
   if (STATS) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {

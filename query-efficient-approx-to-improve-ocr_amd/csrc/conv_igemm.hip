@@ -1337,8 +1337,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
     cur = nxt;
     vb = nvb;
   }
-  qea_amax_commit(am, yamax);
-  if constexpr (PKW != 0) qea_amax_commit(pm, pamax);
+  qea_amax_commit_block(am, yamax);
+  if constexpr (PKW != 0) qea_amax_commit_block(pm, pamax);
 }
 
 // w [N][9][Cin] fp32 -> fragment-ordered planes [chunk][step = tap*KS + cs][plane][nj][lane][8 bf16], chunk width CW (32 or 64

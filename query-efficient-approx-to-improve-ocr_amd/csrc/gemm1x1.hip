@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm1x1_wgs
     vb = nvb;
     par ^= 1;
   }
-  qea_amax_commit(am, p.yamax);                            // once per workgroup, after its last item (not an L2 round trip per item)
+  qea_amax_commit_block(am, p.yamax);                      // once per workgroup, after its last item (not an L2 round trip per item)
 }
 
 template <int CIN, int WM, int NJ>
