@@ -980,7 +980,9 @@ int launch_halo(const ConvArgs& a, hipStream_t s) {
 #endif
 // workgroups per CU: two where the LDS allows no more; three for the narrow fp16 instances (<= 52 KB of LDS each), whose tiles are
 // bound by the latency of their halo gather and stores, not by the MFMA pipe
-constexpr int halo_bf3_wgs(int cin, int cout, int npl) { return (npl == 2 && cout <= 64 && (cin == 32 || cout == 32) && QEA_HALO_NARROW_WGS == 3) ? 3 : 2; }
+constexpr int halo_bf3_wgs(int cin, int cout, int npl, bool bst = false) {
+  return (npl == 2 && cout <= 64 && (cin == 32 || cout == 32) && !(bst && cout == 64) && QEA_HALO_NARROW_WGS == 3) ? 3 : 2;   // (the 32->64 instance with the BatchNorm-backward sums spills at 168 registers)
+}
 
 // PKW != 0 (round 3): the max-pool that follows the layer leaves with the epilogue — window 2 x PKW over the STORED values (after scale /
 // bias / ReLU), scan order and NaN rule of maxpool_fwd_kernel, written to `pooled` (pixel stride ldp) next to the full-resolution
@@ -989,7 +991,7 @@ constexpr int halo_bf3_wgs(int cin, int cout, int npl) { return (npl == 2 && cou
 // per (pixel tile, wave row) and output column, the fp64 partial sums of dz = da * [scale * yref + shift > 0] and of dz * (yref - mean) *
 // invstd — what colreduce_kernel<1> computes in a pass of its own over da and yref (the partials' layout is the STATS one).
 template <int CIN, int COUT, int TH, bool STATS, int IMW = 0, int NPL = 3, int PKW = 0, bool BST = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wgs(CIN, COUT, NPL), halo_bf3_wgs(CIN, COUT, NPL)))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wgs(CIN, COUT, NPL, BST), halo_bf3_wgs(CIN, COUT, NPL, BST)))) void conv3x3_halo_bf3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wf, float* __restrict__ y,
                                                                int B, int H, int W, int ldx, int ldy, const float* __restrict__ scale,
                                                                const float* __restrict__ bias, int relu, double* __restrict__ stats, int chunks,
                                                                int Ntot, const float* __restrict__ mask, int ldmask, int total,
@@ -1287,42 +1289,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
         }
       }
     } else {
+      // The option tests (scale / bias / ReLU / mask: the same for every element) sit OUTSIDE the element loops, the accumulators are
+      // finished in place, and a tile row's addresses are a uniform 64-bit row base + a 32-bit lane / column offset.  (The first form
+      // tested the options and multiplied 64-bit pixel indices per element: 2900 instructions and 316 branches for 64 stores, with
+      // spilled scalar registers read back lane by lane — 12-35 % on top of a tile's MFMA time.)
+      if constexpr (F16) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
-        size_t prow;                                    // pixel index of (tile row wm * MI + i, tile column px) in the [B*H*W] row space
-        bool live = true;
-        if (SMALL) {
-          const int img = (i / IMH) * IPX + px / IMW;
-          prow = ((size_t)(cur.b + img) * IMH + i % IMH) * IMW + px % IMW;
-          live = cur.b + img < B;                       // the last tile of an image count that is no multiple of IPX * IPY
-        } else {
-          prow = (size_t)(cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0 + px;
-        }
-        float v = acc[i][r];
-        if constexpr (F16) v = (v * inv_x) * inv_w;       // un-scale: exact (powers of two), one factor at a time (their product may leave the fp32 range)
-        if (scale && bias) v = __fmaf_rn(v, esc, ebi);
-        else if (scale) v *= esc;
-        else if (bias) v += ebi;
-        if (relu) v = fmaxf(v, 0.f);
-        if (!live) continue;
-        if (mask) v = (mask[prow * ldmask + n] > 0.f) ? v : 0.f;   // ReLU mask of another tensor (input gradient through a bare ReLU)
-        y[prow * ldy + n] = v;
-        am = qea_amax_acc(am, v);
-        if (STATS) {
-          st0 += (double)v;
-          st1 += (double)v * (double)v;
-        }
-        if constexpr (BST) {                            // (the very mask and the very terms of colreduce_kernel<1>)
-          const float yv = yref[prow * ldyref + n];
-          const float dz = __fmaf_rn(yv, msc, msh) > 0.f ? v : 0.f;
-          st0 += (double)dz;
-          st1 += (double)dz * (((double)yv - bmu) * bis);
-        }
+          for (int r = 0; r < 16; ++r) acc[i][r] = (acc[i][r] * inv_x) * inv_w;   // un-scale: exact (powers of two), one factor at a time
       }
-    }
+      if (scale && bias) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = __fmaf_rn(acc[i][r], esc, ebi);
+      } else if (scale) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] *= esc;
+      } else if (bias) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] += ebi;
+      }
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = fmaxf(acc[i][r], 0.f);
+      }
+      auto store_rows = [&](auto has_mask) {
+        constexpr bool HAS_MASK = decltype(has_mask)::value;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          // non-SMALL: pixel (tile row wm * MI + i, column px) = row base (uniform over the wave) + px, px = c(r) + 4 fh
+          const int rowpix = (cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0;
+          float* yb = y + (size_t)rowpix * ldy;
+          const float* mb = HAS_MASK ? mask + (size_t)rowpix * ldmask : nullptr;
+          const float* rb = BST ? yref + (size_t)rowpix * ldyref : nullptr;
+          const int lo = 4 * fh * ldy + n, lom = 4 * fh * ldmask + n, lor = 4 * fh * ldyref + n;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            float v = acc[i][r];
+            size_t prow = 0;
+            if (SMALL) {                                  // several images per tile: per-element image / row / column
+              const int px = c + 4 * fh;
+              const int img = (i / IMH) * IPX + px / IMW;
+              prow = ((size_t)(cur.b + img) * IMH + i % IMH) * IMW + px % IMW;
+              if (cur.b + img >= B) continue;             // the last tile of an image count that is no multiple of IPX * IPY
+              if (HAS_MASK) v = (mask[prow * ldmask + n] > 0.f) ? v : 0.f;
+              y[prow * ldy + n] = v;
+            } else {
+              if (HAS_MASK) v = (mb[lom + c * ldmask] > 0.f) ? v : 0.f;   // ReLU mask of another tensor (input gradient through a bare ReLU)
+              yb[lo + c * ldy] = v;
+            }
+            am = qea_amax_acc(am, v);
+            if (STATS) {
+              st0 += (double)v;
+              st1 += (double)v * (double)v;
+            }
+            if constexpr (BST) {                          // (the very mask and the very terms of colreduce_kernel<1>)
+              const float yv = SMALL ? yref[prow * ldyref + n] : rb[lor + c * ldyref];
+              const float dz = __fmaf_rn(yv, msc, msh) > 0.f ? v : 0.f;
+              st0 += (double)dz;
+              st1 += (double)dz * (((double)yv - bmu) * bis);
+            }
+          }
+        }
+      };
+      if (mask) store_rows(std::true_type{});
+      else store_rows(std::false_type{});
     }
     if (STATS || BST) {                                        // one partial per (pixel tile, wave row): [blocks][Ntot][2]
       const double sa = st0 + __shfl_xor(st0, 32, 64);
@@ -1425,7 +1465,7 @@ int launch_halo_bf3_(const ConvArgs& a, hipStream_t s) {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return halo_bf3_wgs(CIN, COUT, NPL) * (cus & ~7);
+    return halo_bf3_wgs(CIN, COUT, NPL, BST) * (cus & ~7);
   }();
   // (32-channel outputs keep one item per workgroup: two persistent workgroups of a CU fall into lockstep there — both staging,
   // then both in their MFMA phase — and lose the overlap that staggered dispatch gives: 150-159 vs 159-166 TFLOP/s measured)
