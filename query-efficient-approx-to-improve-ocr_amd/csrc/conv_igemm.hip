@@ -1288,6 +1288,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
           pm = qea_amax_acc(pm, m);
         }
       }
+    } else if constexpr (BST) {
+      // (the instances with the BatchNorm-backward sums keep the per-element form: in the hoisted form below their fp64 sums and the
+      //  second row base spill — 819 -> 1251 us on the 32x128 level)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = (r & 3) + 8 * (r >> 2) + 4 * fh;
+          size_t prow;
+          bool live = true;
+          if (SMALL) {
+            const int img = (i / IMH) * IPX + px / IMW;
+            prow = ((size_t)(cur.b + img) * IMH + i % IMH) * IMW + px % IMW;
+            live = cur.b + img < B;
+          } else {
+            prow = (size_t)(cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0 + px;
+          }
+          float v = acc[i][r];
+          if constexpr (F16) v = (v * inv_x) * inv_w;
+          if (scale && bias) v = __fmaf_rn(v, esc, ebi);
+          else if (scale) v *= esc;
+          else if (bias) v += ebi;
+          if (relu) v = fmaxf(v, 0.f);
+          if (!live) continue;
+          if (mask) v = (mask[prow * ldmask + n] > 0.f) ? v : 0.f;
+          y[prow * ldy + n] = v;
+          am = qea_amax_acc(am, v);
+          const float yv = yref[prow * ldyref + n];       // (the very mask and the very terms of colreduce_kernel<1>)
+          const float dz = __fmaf_rn(yv, msc, msh) > 0.f ? v : 0.f;
+          st0 += (double)dz;
+          st1 += (double)dz * (((double)yv - bmu) * bis);
+        }
+      }
     } else {
       // The option tests (scale / bias / ReLU / mask: the same for every element) sit OUTSIDE the element loops, the accumulators are
       // finished in place, and a tile row's addresses are a uniform 64-bit row base + a 32-bit lane / column offset.  (The first form
@@ -1329,8 +1362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
           const int rowpix = (cur.b * H + cur.y0 + wm * MI + i) * W + cur.x0;
           float* yb = y + (size_t)rowpix * ldy;
           const float* mb = HAS_MASK ? mask + (size_t)rowpix * ldmask : nullptr;
-          const float* rb = BST ? yref + (size_t)rowpix * ldyref : nullptr;
-          const int lo = 4 * fh * ldy + n, lom = 4 * fh * ldmask + n, lor = 4 * fh * ldyref + n;
+          const int lo = 4 * fh * ldy + n, lom = 4 * fh * ldmask + n;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int c = (r & 3) + 8 * (r >> 2);
@@ -1351,12 +1383,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
             if (STATS) {
               st0 += (double)v;
               st1 += (double)v * (double)v;
-            }
-            if constexpr (BST) {                          // (the very mask and the very terms of colreduce_kernel<1>)
-              const float yv = SMALL ? yref[prow * ldyref + n] : rb[lor + c * ldyref];
-              const float dz = __fmaf_rn(yv, msc, msh) > 0.f ? v : 0.f;
-              st0 += (double)dz;
-              st1 += (double)dz * (((double)yv - bmu) * bis);
             }
           }
         }
