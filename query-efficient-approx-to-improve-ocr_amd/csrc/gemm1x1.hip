@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm1x1_wgs
     }
 
     // ---- epilogue: v = acc / (s_x s_w) + bias; ReLU; store.  Accumulator row = (r & 3) + 8 (r >> 2) + 4 fh of block i, column fr.
+    // The option tests sit outside the element loops and the accumulators are finished in place (as in the LDS-halo conv).
     const int* rp = rowpix + par * BM;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -189,18 +190,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm1x1_wgs
         ncol = nbias = n - ab * co_n;
         dpix = (ab >> 1) * (2 * p.OW) + (ab & 1);
       }
-      const float ebi = p.bias ? p.bias[nbias] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * inv_x) * inv_w;   // un-scale: exact (powers of two), one factor at a time
+      if (p.bias) {
+        const float ebi = p.bias[nbias];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += ebi;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+      }
+      float* yc = p.y + (size_t)dpix * p.ldy + ncol;       // this lane's column (+ the scatter's pixel shift)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          const int pix = rp[row];
-          float v = (acc[i][j][r] * inv_x) * inv_w;       // un-scale: exact (powers of two), one factor at a time
-          if (p.bias) v += ebi;
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (pix < 0) continue;
-          p.y[(size_t)(pix + dpix) * p.ldy + ncol] = v;
+          const int pix = rp[(wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh];
+          if (pix < 0) continue;                          // row past M
+          const float v = acc[i][j][r];
+          yc[(size_t)pix * p.ldy] = v;
           am = qea_amax_acc(am, v);
         }
       }
