@@ -31,8 +31,10 @@ __device__ __forceinline__ void qea_split3(const f32x4 v, bf16x4& h, bf16x4& m, 
 
 // TWO-way fp16 split of a SCALED operand (round 3): xs = x * s with s a power of two chosen from the tensor's largest finite
 // magnitude m so that m * s is in [2^14, 2^15) (qea_f16_scale); h = f16(xs) and l = f16(xs - h) carry 11 + 11 significant bits
-// (+ the sign of l): |xs - (h + l)| <= 2^-24 |xs| — as good as the three bf16 pieces — for every element within 2^-29 of m,
-// and an ABSOLUTE error below 2^-40 m for the smaller ones (fp16 subnormal spacing 2^-24 in scaled units).  A product keeps hh,
+// (+ the sign of l): |xs - (h + l)| <= 2^-24 |xs| — as good as the three bf16 pieces — for every element down to about 2^-16 of m
+// (|xs| >= 1/2: the residual's last fp32 bit is then still >= 2^-24, the spacing of the SUBNORMAL fp16 values l falls into once
+// |xs| < ~2^-3), and an ABSOLUTE error below 2^-25 in scaled units = 2^-40 m for the smaller ones (e.g. ~2^-11 relative at 2^-29 of
+// m: negligible against the rounding of the large terms such an element is summed with).  A product keeps hh,
 // hl, lh (three v_mfma_f32_32x32x16_f16, fp32 accumulate); the dropped ll is < 2^-22 |ab|.  Non-finite elements do not enter m
 // and stay non-finite in h (inf) / l (NaN).
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)

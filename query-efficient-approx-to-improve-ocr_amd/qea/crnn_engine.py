@@ -273,14 +273,14 @@ class CRNNEngine:
             if layer == 1:
                 dxl = torch.empty(T, B, 512, device=dev)
                 ops.conv_igemm(gates, wT, dxl, B=1, H=1, W=TB, Cin=8 * HID, OH=1, OW=TB, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512,
-                               x_amax=g_amax, w_src=("catT", wf))      # (planes of the concatenated filter: cached with the forward weight, both change together)
+                               x_amax=g_amax, w_src=("catT", wf, (wr,)))      # (planes of the concatenated filter: cached with BOTH directions' weights)
                 dy = dxl
             else:
                 # rows (t,b) -> output row b*T + t : the gradient of conv7's output in its own [B,1,T,512] order
                 dseq_bt = torch.empty(B, T, 512, device=dev)
                 dseq_amax = slot()
                 ops.conv_igemm(gates, wT, dseq_bt, B=T, H=1, W=B, Cin=8 * HID, OH=1, OW=B, N=512, KH=1, KW=1, ldx=8 * HID, ldy=512,
-                               out_mode=ops.OUT_TBC, x_amax=g_amax, y_amax=dseq_amax, w_src=("catT", wf))
+                               out_mode=ops.OUT_TBC, x_amax=g_amax, y_amax=dseq_amax, w_src=("catT", wf, (wr,)))
 
         # conv7 (2x2, pad 0) backward
         h6, w6 = ctx["h6"], ctx["w6"]

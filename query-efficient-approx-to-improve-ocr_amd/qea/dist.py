@@ -61,14 +61,15 @@ def allreduce_module_grads(module):
 def global_topk(local_cers, k_global, with_counts=False):
     """TopKCER over the WHOLE minibatch when it is sharded: all-gather the per-shard CERs,
     rank them in the global stable-descending order (rank-major index as the tie-break), and return
-    (local indices of the winners that live in this shard, k_global).  The caller weights its loss
-    by len(local)/k_global so that averaged gradients equal the global-batch mean.
-    with_counts: also return how many winners live on each rank (the input of rebalance_rows)."""
+    (local indices of the winners that live in this shard, k) with k = the number of strips actually picked
+    = min(k_global, minibatch rows) on EVERY path (a minibatch with fewer rows than k_global picks them all).
+    The caller weights its loss by len(local)/k so that averaged gradients equal the global-batch mean.
+    with_counts: also return how many winners live on each rank (the input of rebalance_rows); k == sum(counts)."""
     w, r = world(), rank()
     vals = torch.as_tensor(local_cers, dtype=torch.float32)
     if w == 1:
         order = torch.argsort(-vals, stable=True)[:k_global]
-        return (order, k_global, [order.numel()]) if with_counts else (order, k_global)
+        return (order, order.numel(), [order.numel()]) if with_counts else (order, order.numel())
     n_local = torch.tensor([vals.numel()], dtype=torch.int64)
     sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(w)]
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -85,7 +86,7 @@ def global_topk(local_cers, k_global, with_counts=False):
     start = sum(sizes[:r])
     mine = order[(order >= start) & (order < start + sizes[r])] - start
     if not with_counts:
-        return mine, k_global
+        return mine, order.numel()
     bounds = torch.tensor([0] + sizes).cumsum(0)
     counts = [int(((order >= bounds[i]) & (order < bounds[i + 1])).sum()) for i in range(w)]
     return mine, order.numel(), counts

@@ -72,10 +72,10 @@ def bump_weight_epoch():
     _wepoch[0] += 1
 
 
-def weight_cached(kind, w, build, also=()):
+def weight_cached(kind, w, build, also=(), extra=None):
     """build() -> tensor(s) derived from the weight tensor `w` (and the tensors in `also`) only; cached per (kind, the
     tensor OBJECT) until one of them changes.  Entries die with the tensor object (weakref), so a new tensor that happens
-    to reuse the address of a freed one can never hit."""
+    to reuse the address of a freed one can never hit.  `extra`: any further hashable the value depends on."""
     token = None
     if torch.cuda.is_current_stream_capturing():
         # inside a capture made by qea.graph.GraphedStep a derived form is built once per weight epoch OF THAT CAPTURE (the build
@@ -87,7 +87,7 @@ def weight_cached(kind, w, build, also=()):
     if not WEIGHT_CACHE["on"]:
         return build()
     key = (kind, id(w))
-    ver = (w.data_ptr(), w._version, _wepoch[0], _stream(), token) + tuple((id(t), t.data_ptr(), t._version) for t in also)
+    ver = (w.data_ptr(), w._version, _wepoch[0], _stream(), token, extra) + tuple((id(t), t.data_ptr(), t._version) for t in also)
     hit = _wcache.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is w:
         return hit[1]
@@ -120,8 +120,9 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
                bwd_stats=None):
     """x_planes / w_planes: operands already in the P3 format (a caller that uses a tensor in several launches splits it
     once); when the launch runs on a split-bf16 tile and they are not given, they are made here (one HBM pass each).
-    w_src = (kind, weight tensor): `w` is a function of that weight only (itself: kind "fwd"; its cached flip_transposed /
-    transposed form: "flipT" / "T"), so its planes are cached with it until the weight changes.
+    w_src = (kind, weight tensor[, (further weight tensors)]): `w` is a function of that weight (and of the further ones) only (itself:
+    kind "fwd"; its cached flip_transposed / transposed form: "flipT" / "T"; the BiLSTM's concatenated projections: "catT" of both
+    directions), so its planes are cached with it until one of them changes.
     want_stats: ask for the fused BatchNorm-statistics epilogue; returns (partials [blocks][N][2] fp64, blocks) when the chosen
     kernel has it, else None (the caller then runs bn_train_stats over y).
     pool = (pooled, ldpool, kw, amax slot or None): the 2 x kw max-pool of y leaves with the epilogue (same bits as maxpool_fwd on y) —
@@ -144,7 +145,7 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
             wmax = filter_absmax(w_src, w, Cin, N, Cin)
             _lib.check(L.qea_pack_frag_planes_f16_1x1(_ptr(w), N, Cin, _ptr(wmax), out.data_ptr(), _stream()), "qea_pack_frag_planes_f16_1x1")
             return out
-        frag = weight_cached(("frag1x1", w_src[0], N, Cin), w_src[1], build) if w_src is not None else build()
+        frag = weight_cached(("frag1x1", w_src[0], N, Cin), w_src[1], build, also=tuple(w_src[2]) if len(w_src) > 2 else ()) if w_src is not None else build()
         d.w_frag_planes = frag.data_ptr()
         xmax = x_amax if x_amax is not None else absmax(x, ldx, B * H * W, Cin)
         d.x_absmax = xmax.data_ptr()
@@ -161,7 +162,7 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
             out = torch.empty(L.qea_pack_frag_planes_bytes(N, Cin), dtype=torch.uint8, device=x.device)
             _lib.check(L.qea_pack_frag_planes(_ptr(w), N, Cin, out.data_ptr(), _stream()), "qea_pack_frag_planes")
             return out
-        frag = weight_cached(("fragf16" if f16 else "frag", w_src[0], N, Cin), w_src[1], build) if w_src is not None else build()
+        frag = weight_cached(("fragf16" if f16 else "frag", w_src[0], N, Cin), w_src[1], build, also=tuple(w_src[2]) if len(w_src) > 2 else ()) if w_src is not None else build()
         d.w_frag_planes = frag.data_ptr()
         if f16:
             # the input's abs-max: carried by the tensor's producer (x_amax), else one pass over the input here
@@ -177,7 +178,7 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
             f16 = SPLIT_F16["on"] and x_planes is None and w_planes is None and N * K * 4 < (1 << 31) - 256
             if w_planes is None:
                 build = (lambda: split_planes_f16(w, K, N, K, w_src)) if f16 else (lambda: split_planes(w, K, N, K))
-                w_planes = weight_cached(("planesf16" if f16 else "planes", w_src[0], N, K), w_src[1], build) if w_src is not None else build()
+                w_planes = weight_cached(("planesf16" if f16 else "planes", w_src[0], N, K), w_src[1], build, also=tuple(w_src[2]) if len(w_src) > 2 else ()) if w_src is not None else build()
             d.x_planes = x_planes.data_ptr() if x_planes is not None else None
             d.w_planes = w_planes.data_ptr()
             if f16:                                       # hybrid tile on the two-way fp16 split: the activations' abs-max
@@ -294,7 +295,10 @@ def filter_absmax(w_src, w, ld, M, Cc):
     fs = flat_state_of(w_src[1], check=False) if w_src is not None else None
     if fs is None or fs.total % 4 or fs.data.data_ptr() > w_src[1].data_ptr() or w_src[1].data_ptr() >= fs.data.data_ptr() + 4 * fs.total:
         return absmax(w, ld, M, Cc)
-    return weight_cached("flat_absmax", fs.data, lambda: absmax(fs.data, fs.total, 1, fs.total))
+    # keyed on the version counters of ALL the model's parameters (fs.vsum, refreshed by the engines' ensure_flat() walk before
+    # every forward): a torch-side write to one re-homed parameter moves that parameter's _version, not the flat buffer's, and a
+    # bound taken before e.g. load_state_dict would scale the new, larger filter to inf in its h plane
+    return weight_cached("flat_absmax", fs.data, lambda: absmax(fs.data, fs.total, 1, fs.total), extra=fs.vsum)
 
 
 def split_planes_f16(x, ld, M, Cc, w_src=None):

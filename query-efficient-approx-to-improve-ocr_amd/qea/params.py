@@ -80,11 +80,21 @@ class FlatState:
             v.copy_(b)
             _set_buffer(module, n, v)
         self._ptrs = [p.data_ptr() for _, p in self.params]
+        self.vsum = sum(p._version for _, p in self.params)
 
     def intact(self):
-        """False if something (e.g. module.to(), load of a pickled checkpoint) re-homed a parameter."""
+        """False if something (e.g. module.to(), load of a pickled checkpoint) re-homed a parameter.
+        The same walk records `vsum`, the sum of the parameters' version counters: the parameters are views re-homed with
+        `p.data = view`, so a torch-side write to ONE of them (load_state_dict, p.copy_, a torch.optim step) moves that parameter's
+        _version and not the flat buffer's — anything derived from the WHOLE buffer (qea.ops.filter_absmax) is keyed on vsum."""
         ps = self.params
-        return all(p.data_ptr() == q for (_, p), q in zip(ps, self._ptrs))
+        ok = True
+        vs = 0
+        for (_, p), q in zip(ps, self._ptrs):
+            ok = ok and p.data_ptr() == q
+            vs += p._version
+        self.vsum = vs
+        return ok
 
     def attach_grads(self):
         """Make every p.grad the view into the flat gradient buffer again.  A gradient that was

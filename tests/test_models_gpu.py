@@ -623,3 +623,35 @@ def test_bn_backward_sums_from_the_dgrad_epilogue():
     xh = ((yref.double() - st[0]) * st[1]).reshape(-1, Cc)
     assert (part[:, 0] - dz.sum(0).cpu()).abs().max().item() <= 1e-9 * dz.abs().sum(0).max().item()
     assert (part[:, 1] - (dz * xh).sum(0).cpu()).abs().max().item() <= 1e-9 * (dz * xh).abs().sum(0).max().item()
+
+
+def test_weights_loaded_after_a_forward_get_a_fresh_filter_scale():
+    """the fp16 planes of every filter are scaled from ONE abs-max of the model's flat parameter buffer; the
+    parameters are views re-homed with `p.data = view`, so load_state_dict / p.copy_ move the PARAMETER's version counter and not the
+    buffer's.  Forward, load weights 8x larger (the old bound would put them at inf in the h plane), forward again: the second result
+    must be the oracle's for the new weights, and finite."""
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea import ops
+    if ops.mfma_mode() != "split_f16":
+        pytest.skip("the scale only exists in the fp16 split")
+    torch.manual_seed(5)
+    net = _load(UNet(), mo.unet_state_shapes, 3).eval()
+    x = torch.rand(2, 1, 32, 128).cuda()
+    with torch.no_grad():
+        y0 = net(x)
+        big = {k: (v * 8 if (v.dtype == torch.float32 and k.endswith("weight") and v.dim() == 4) else v) for k, v in mo.seeded_state(mo.unet_state_shapes(), 3).items()}
+        net.load_state_dict(big)
+        y1 = net(x)
+        sd = {k: v.double() for k, v in big.items()}
+        want = mo.unet_forward(sd, x.cpu().double(), train=False)[0] if hasattr(mo, "unet_forward") else None
+    assert torch.isfinite(y1).all()
+    assert not torch.equal(y0, y1)
+    if want is not None:
+        assert _rel(y1, want.float()) < 1e-4
+    # ... and a write to ONE parameter through torch (copy_) is seen too
+    with torch.no_grad():
+        p = net.encoder1.enc1conv2.weight if hasattr(net, "encoder1") and hasattr(net.encoder1, "enc1conv2") else next(q for q in net.parameters() if q.dim() == 4 and q.shape[1] > 1)
+        p.copy_(p * 16)
+        y2 = net(x)
+    assert torch.isfinite(y2).all()
