@@ -271,6 +271,17 @@ def main():
 
     noiser = AddGaussianNoice(std=5, is_stochastic=True)
 
+    # self-diagnosis of the data-parallel legs: HIP events on the compute stream around the two gradient all-reduces
+    # (the stream waits for the collective, so the pair brackets it), the rows each rank ran through Phase A after the re-balance
+    dp_stats = {"events": {"unet": [], "crnn": []}, "phase_a_rows": 0}
+
+    def timed_allreduce(buf, which):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_reduce(buf)
+        e1.record()
+        dp_stats["events"][which].append((e0, e1))
+
     def cer_update(w):
         """train_nn_area.py:290-304: pred_to_string -> compare_labels per sample -> sampler.update_cer"""
         w.sampler.update_cer(batch_cers(w.last_lp, w.labels, c2i), w.names)
@@ -289,7 +300,7 @@ def main():
         w.last_lp = lp.detach()
         loss.backward()
         if use_dist:
-            dist.all_reduce(fs.grad)                 # one RCCL all-reduce of the flat 31 MB UNet gradient
+            timed_allreduce(fs.grad, "unet")         # one RCCL all-reduce of the flat 31 MB UNet gradient
             if world > 1:
                 fs.grad.mul_(1.0 / world)
         opt_p.step()
@@ -332,8 +343,9 @@ def main():
             yA = torch.cat([w.y[int(w.off[i]):int(w.off[i + 1])] for i in sel])
             lossA = ctc(lpA[:, (R - 1) * k:, :], yA, torch.full((k,), 31, dtype=torch.int32), w.lens[idx.cpu()])
             (lossA * share if share != 1.0 else lossA).backward()      # area flow: last replica only
+        dp_stats["phase_a_rows"] = k                 # rows this rank ran through Phase A (after the winner re-balance)
         if use_dist:
-            dist.all_reduce(fc.grad)                 # flat 35 MB CRNN gradient; the second all-reduce of the step
+            timed_allreduce(fc.grad, "crnn")         # flat 35 MB CRNN gradient; the second all-reduce of the step
             if world > 1:
                 fc.grad.mul_(1.0 / world)
         opt_c.step()
@@ -382,7 +394,21 @@ def main():
         from qea.graph import GraphedStep
         run = GraphedStep(lambda: phase_b(W), warmup=0)
         run()
+    for v in dp_stats["events"].values():
+        v.clear()                                    # only the timed region's collectives are reported
     dt, loss = timed(run, args.steps)
+    dp_report = None
+    if use_dist:
+        torch.cuda.synchronize()
+        ar = {k: sum(a.elapsed_time(b) for a, b in v) / max(args.steps, 1) for k, v in dp_stats["events"].items()}
+        rows = [None] * world
+        dist.all_gather_object(rows, int(dp_stats["phase_a_rows"]))
+        dp_report = {"rccl_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                     "allreduce_ms": {"crnn_after_phase_a": ar["crnn"], "unet_after_phase_b": ar["unet"], "per_step": ar["crnn"] + ar["unet"],
+                                      "note": "HIP events on the compute stream around dist.all_reduce, mean per timed step on rank 0"},
+                     "phase_a_rows_per_rank": rows}
+        for v in dp_stats["events"].values():
+            v.clear()
     if rank == 0:
         print(f"[bench] {args.steps} timed steps in {dt:.3f}s", file=sys.stderr, flush=True)
     # ---- Phase B alone at the same batch (the per-image unit of SURVEY.md §8d)
@@ -517,6 +543,7 @@ def main():
                        "crnn_wgrad": not args.skip_crnn_wgrad, "parallelism": f"dp{world}",
                        "collectives_per_step": 0 if not use_dist else (1 if args.phase_b_only else 2),
                        "small_collectives_per_step": 0 if (world == 1 or args.phase_b_only) else "CER all-gather (4 B per strip) + winner re-balance (k x 16 KB)",
+                       "data_parallel": dp_report,
                        "loss": float(loss.item()), "hipgraph": bool(args.graph)},
             "phase_b": None if (args.no_phase_b_leg and not args.phase_b_only) else {"value": imgs / dt_b, "unit": "patch-images/s", "ms_per_step": dt_b / args.steps * 1e3,
                         "end_to_end_tflops": FLOP_PER_IMG_FAITHFUL * imgs / dt_b / 1e12 if not args.skip_crnn_wgrad else None,

@@ -169,3 +169,14 @@ def test_levenshtein_and_attention_weight_generators():
     assert wa.shape == (3, 4) and (wa[0, 1:] > 0).all() and (wa[0, 1:] < 1).all() and wa[1, 2:].abs().sum() == 0
     assert set(att.attention_model.state_dict().keys()) == {"positional_encodings", "embedding", "Wq.weight", "Wq.bias",
                                                             "loss_coef_layer.weight", "loss_coef_layer.bias"}
+
+
+def test_global_topk_reports_the_picked_count_when_the_minibatch_is_smaller_than_k():
+    """with fewer rows than k_global every row is picked and k is that number on every path (share = world * n / k)."""
+    from qea import dist as qdist
+    order, k = qdist.global_topk([0.3, 0.9], 5)
+    assert order.tolist() == [1, 0] and k == 2
+    order, k, counts = qdist.global_topk([0.3, 0.9], 5, with_counts=True)
+    assert k == 2 and counts == [2] and k == sum(counts)
+    order, k = qdist.global_topk([0.1, 0.5, 0.4], 2)
+    assert order.tolist() == [1, 2] and k == 2

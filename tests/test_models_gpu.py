@@ -643,12 +643,11 @@ def test_weights_loaded_after_a_forward_get_a_fresh_filter_scale():
         big = {k: (v * 8 if (v.dtype == torch.float32 and k.endswith("weight") and v.dim() == 4) else v) for k, v in mo.seeded_state(mo.unet_state_shapes(), 3).items()}
         net.load_state_dict(big)
         y1 = net(x)
-        sd = {k: v.double() for k, v in big.items()}
-        want = mo.unet_forward(sd, x.cpu().double(), train=False)[0] if hasattr(mo, "unet_forward") else None
+        P, Bf = mo.split_state({k: (v.double() if v.is_floating_point() else v) for k, v in big.items()}, requires_grad=False)
+        want = mo.unet_forward(P, Bf, x.cpu().double(), False)
     assert torch.isfinite(y1).all()
     assert not torch.equal(y0, y1)
-    if want is not None:
-        assert _rel(y1, want.float()) < 1e-4
+    assert _rel(y1, want.float()) < 1e-4
     # ... and a write to ONE parameter through torch (copy_) is seen too
     with torch.no_grad():
         p = net.encoder1.enc1conv2.weight if hasattr(net, "encoder1") and hasattr(net.encoder1, "enc1conv2") else next(q for q in net.parameters() if q.dim() == 4 and q.shape[1] > 1)
