@@ -222,7 +222,8 @@ typedef struct qea_wgrad_desc {
   int32_t ldp, ldq;
   int32_t accumulate; /* dw += result                                                     */
   int32_t splits;     /* 0 = auto                                                         */
-  int32_t tile;       /* 0 = auto                                                         */
+  int32_t tile;       /* 0 = auto; 23 = the nine-tap LDS-halo kernel (with both abs-max pointers and R, C multiples of 64: its
+                       * producer / consumer form, round 4), 29 = the nine-tap kernel in the round-3 form (every wave stages) */
   /* ABI v6: when BOTH are non-NULL (device pointers to one float each: qea_absmax of p and of q) a launch that runs on a split tile —
    * the nine-tap LDS-halo kernel (3x3 pad 1 stride 1, PW in {16, 32k}, R and C multiples of 32) or tiles 20-22 — takes the TWO-way
    * fp16 split: three MFMAs per product instead of six (see qea_conv_desc.x_absmax).  Other launches ignore them. */

@@ -819,6 +819,7 @@ void launch_halo(const qea_wgrad_desc* d, const HaloPlan& h, hipStream_t s) {
 struct Halo9Plan {
   bool ok;
   int sw, th, tiles_x, tiles_y, n_tiles, r_blks, c_blks, splits, rb, cb, wk;
+  int spec;   // the producer / consumer form (wgrad_halo9_spec_kernel): two-way fp16 split, 64 x 64 blocks, tile 0 / 23
 };
 
 constexpr int H9_HP_MAX = 136;   // halo pixels: (2+2) x (32+2) or (4+2) x (16+2) = 108
@@ -1027,8 +1028,194 @@ void wgrad_halo9_bf3_kernel(const float* __restrict__ p, const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the nine-tap kernel as PRODUCER / CONSUMER waves (two-way fp16 split, 64 x 64 channel blocks; tools/micro/wgrad_lab.hip
+// measured it: 299 -> 381 TFLOP/s at 256 x 256 channels, 8 x 32 pixels, B = 2048).  In the kernel above every wave gathers, splits,
+// stores, waits at two barriers and only then multiplies: staging was 46 % of a tile's MFMA time and the matrix pipe 0.41 busy.  Here a
+// workgroup has EIGHT waves: waves 0-3 (one per SIMD) only run MFMAs — each a 32 x 32 sub-block, nine accumulator tiles — and waves
+// 4-7 (their SIMD partners) gather, split and write the NEXT 64-pixel tile into the other of two LDS buffers (50 KB each) while the
+// consumers read this one: ONE barrier per tile, the split's VALU work beside the MFMAs instead of in front of them.  One workgroup
+// per CU (100 KB of LDS), the pixel tiles dealt over 256 / (channel blocks) splits; slabs and their fixed-order reduction as above.
+// Same LDS rows (pixels x 64 channels, 64-byte chunks swapped by (pixel >> 1) & 1), same products in the same order per tile as the
+// kernel above — the slab layout (one per split) and the number of splits differ, so the two forms agree to fp32 rounding, not bit
+// for bit; each is bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f16x8 tr_pair128(const char* base) {   // this lane's 4-pixel block and the block 4 pixel rows (512 bytes) further
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + 4 * 128));
+  return __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int SW>
+constexpr size_t halo9_spec_lds() { return (size_t)2 * (2 * 64 * 64 * 2 + 2 * ((64 / SW + 2) * (SW + 2)) * 64 * 2); }
+
+template <int SW>
+__global__ __launch_bounds__(512) void wgrad_halo9_spec_kernel(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ ws, int B,
+                                                               int H, int W, int R, int C, int ldp, int ldq, Halo9Plan hp,
+                                                               const float* __restrict__ pmax, const float* __restrict__ qmax) {
+  constexpr int TH = 64 / SW, HWD = SW + 2, HH = TH + 2, HP = HH * HWD;
+  constexpr int P_PLANE_B = 64 * 64 * 2, Q_PLANE_B = HP * 64 * 2;            // bytes per plane
+  constexpr int BUF_B = 2 * P_PLANE_B + 2 * Q_PLANE_B;                        // one buffer: P h, P l, Q h, Q l
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  float sp, sq, inv_p, inv_q;
+  qea_f16_scale(pmax[0], sp, inv_p);
+  qea_f16_scale(qmax[0], sq, inv_q);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = qea_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int c_blk = bid % hp.c_blks;
+  bid /= hp.c_blks;
+  const int r_blk = bid % hp.r_blks;
+  const int split = bid / hp.r_blks;
+  const int r0 = r_blk * 64, c0 = c_blk * 64;
+  const int ntl = (hp.n_tiles - split + hp.splits - 1) / hp.splits;          // tiles of this workgroup: split, split + splits, ...
+
+  if (wave >= 4) {
+    // ---------------------------------------------------------------- producers
+    const int pt = tid - 256;
+    constexpr int NP = 64 * 16 / 256, NQ = (HP * 16 + 255) / 256;
+    f32x4 preg[NP], qreg[NQ];
+    auto fetch = [&](int tile) {
+      const int tx = tile % hp.tiles_x;
+      const int ty = (tile / hp.tiles_x) % hp.tiles_y;
+      const int b = tile / (hp.tiles_x * hp.tiles_y);
+      const int x0 = tx * SW, y0 = ty * TH;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int e = pt + 256 * i;
+        const int c4 = e % 16, pix = e / 16;
+        const int py = pix / SW, px = pix - py * SW;
+        preg[i] = *reinterpret_cast<const f32x4*>(p + ((size_t)(b * H + y0 + py) * W + x0 + px) * ldp + r0 + c4 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int e = pt + 256 * i;
+        const int c4 = e % 16, hq = e / 16;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (hq < HP) {
+          const int hy = hq / HWD, hx = hq - hy * HWD;
+          const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(q + ((size_t)(b * H + iy) * W + ix) * ldq + c0 + c4 * 4);
+        }
+        qreg[i] = v;
+      }
+    };
+    auto row_off = [](int pix, int c4) { return pix * 64 + ((((c4 >> 3) ^ (pix >> 1)) & 1) << 5) + (c4 & 7) * 4; };   // 16-bit elements
+    auto stage = [&](char* buf) {
+      _Float16* Ps = reinterpret_cast<_Float16*>(buf);
+      _Float16* Qs = reinterpret_cast<_Float16*>(buf + 2 * P_PLANE_B);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int e = pt + 256 * i;
+        const int o = row_off(e / 16, e % 16);
+        f16x4 h, l;
+        qea_split2_f16(preg[i], sp, h, l);
+        *reinterpret_cast<f16x4*>(Ps + o) = h;
+        *reinterpret_cast<f16x4*>(Ps + P_PLANE_B / 2 + o) = l;
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int e = pt + 256 * i;
+        const int hq = e / 16;
+        if (hq < HP) {
+          const int o = row_off(hq, e % 16);
+          f16x4 h, l;
+          qea_split2_f16(qreg[i], sq, h, l);
+          *reinterpret_cast<f16x4*>(Qs + o) = h;
+          *reinterpret_cast<f16x4*>(Qs + Q_PLANE_B / 2 + o) = l;
+        }
+      }
+    };
+    if (ntl > 0) {
+      fetch(split);
+      stage(lds);
+      if (ntl > 1) fetch(split + hp.splits);
+    }
+    __syncthreads();                                         // tile 0 staged
+    for (int t = 0; t < ntl; ++t) {
+      if (t + 1 < ntl) stage(lds + ((t + 1) & 1) * BUF_B);
+      if (t + 2 < ntl) fetch(split + (t + 2) * hp.splits);
+      __syncthreads();                                       // consumers done with buffer t & 1, buffer (t + 1) & 1 complete
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumers
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // transposing-read geometry: pixel (g16 >> 1) * 8 + tq (+ 4 for the second read) of a 16-pixel k-step, channels (g16 & 1) * 16 + tpp * 4
+  const int g16 = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
+  const int l_pix = (g16 >> 1) * 8 + tq;
+  const int l_ch = (g16 & 1) * 16 + tpp * 4;
+  // P fragment of k-step ks: LDS pixel row ks * 16 + l_pix (ks * 16 is a multiple of 4: the chunk swap only depends on l_pix)
+  const int p_off = l_pix * 128 + ((((wr ^ (l_pix >> 1)) & 1) << 5) + l_ch) * 2;
+  // Q fragment at halo pixel c + l_pix (c a compile-time tap offset): the chunk swap follows the parity of (c + l_pix) >> 1 -> four
+  // loop-invariant bases by (c & 1, (c >> 1) & 1) and an immediate c * 128
+  int TQ[2][2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int hs = (par ? (l_pix + 1) >> 1 : l_pix >> 1) + b;
+      TQ[par][b] = l_pix * 128 + ((((wc ^ hs) & 1) << 5) + l_ch) * 2;
+    }
+  __syncthreads();                                           // tile 0 staged
+  for (int t = 0; t < ntl; ++t) {
+    const char* buf = lds + (t & 1) * BUF_B;
+    const char* Pb = buf + p_off;
+    const char* Qb = buf + 2 * P_PLANE_B;
+    auto read_p = [&](int ks, f16x8* af) {
+      af[0] = tr_pair128(Pb + ks * 16 * 128);
+      af[1] = tr_pair128(Pb + P_PLANE_B + ks * 16 * 128);
+    };
+    auto read_q = [&](int f, f16x8* bf) {                   // f = ks * 9 + tap
+      const int ks = f / 9, tap = f % 9;
+      const int py = (ks * 16) / SW, px0 = (ks * 16) % SW;
+      const int c = (py + tap / 3) * HWD + px0 + tap % 3;
+      const char* src = Qb + TQ[c & 1][(c >> 1) & 1] + c * 128;
+      bf[0] = tr_pair128(src);
+      bf[1] = tr_pair128(src + Q_PLANE_B);
+    };
+    f16x8 af[2][2], bq[2][2];
+    read_p(0, af[0]);
+    read_q(0, bq[0]);
+#pragma unroll
+    for (int f = 0; f < 36; ++f) {
+      const int ks = f / 9, tap = f % 9;
+      const f16x8* a = af[ks & 1];
+      const f16x8* b = bq[f & 1];
+      if (f + 1 < 36) read_q(f + 1, bq[(f + 1) & 1]);
+      if (tap == 0 && ks + 1 < 4) read_p(ks + 1, af[(ks + 1) & 1]);
+      // smallest terms first (ll is dropped): lh, hl, hh
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc[tap], 0, 0, 0);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc[tap], 0, 0, 0);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc[tap], 0, 0, 0);
+      if (f + 1 < 36) {
+        if (tap == 0 && ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = ws + (size_t)split * R * 9 * C;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = r0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      out[((size_t)rr * 9 + t) * C + c0 + wc * 32 + fr] = (acc[t][r] * inv_p) * inv_q;
+    }
+}
+
 Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
-  Halo9Plan h = {false, 0, 0, 0, 0, 0, 0, 0, 0, 64, 64, 1};
+  Halo9Plan h = {false, 0, 0, 0, 0, 0, 0, 0, 0, 64, 64, 1, 0};
   if (d->KH != 3 || d->KW != 3 || d->pad_h != 1 || d->pad_w != 1 || d->stride_h != 1 || d->stride_w != 1 || d->PH != d->QH || d->PW != d->QW) return h;
   if (d->R % 32 || d->C % 32) return h;
   h.sw = (d->PW % 32 == 0) ? 32 : (d->PW == 16 ? 16 : 0);
@@ -1047,8 +1234,11 @@ Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
   h.wk = 4 / ((h.rb / 32) * (h.cb / 32));                    // k-step shares (separate slabs)
   h.r_blks = d->R / h.rb;
   h.c_blks = d->C / h.cb;
-  // two workgroups per CU (77 KB of LDS each): about 512 workgroups, each walking at least 8 tiles
-  int splits = d->splits > 0 ? d->splits : 512 / (h.r_blks * h.c_blks);
+  // tile 29 keeps the round-3 form (every wave stages, then multiplies) where the producer / consumer form would run
+  h.spec = (h.rb == 64 && d->p_absmax && d->q_absmax && d->tile != 29) ? 1 : 0;
+  // two workgroups per CU (77 KB of LDS each): about 512 workgroups, each walking at least 8 tiles; the producer / consumer form:
+  // one 8-wave workgroup per CU (100 KB)
+  int splits = d->splits > 0 ? d->splits : (h.spec ? 256 : 512) / (h.r_blks * h.c_blks);
   if (splits > h.n_tiles / 8) splits = h.n_tiles / 8;
   if (splits < 1) splits = 1;
   h.splits = splits;
@@ -1080,7 +1270,23 @@ int launch_halo9_any(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s)
   return (d->p_absmax && d->q_absmax) ? launch_halo9_<SW, RB, CB, 2>(d, h, s) : launch_halo9_<SW, RB, CB, 3>(d, h, s);
 }
 
+template <int SW>
+int launch_halo9_spec(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
+  constexpr size_t lds = halo9_spec_lds<SW>();
+  const long long grid = (long long)h.r_blks * h.c_blks * h.splits;
+  auto kern = wgrad_halo9_spec_kernel<SW>;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h,
+                     d->p_absmax, d->q_absmax);
+  return QEA_OK;
+}
+
 int launch_halo9(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
+  if (h.spec) return h.sw == 32 ? launch_halo9_spec<32>(d, h, s) : launch_halo9_spec<16>(d, h, s);
   if (h.sw == 32) return h.rb == 64 ? launch_halo9_any<32, 64, 64>(d, h, s) : launch_halo9_any<32, 32, 32>(d, h, s);
   return h.rb == 64 ? launch_halo9_any<16, 64, 64>(d, h, s) : launch_halo9_any<16, 32, 32>(d, h, s);
 }
@@ -1093,7 +1299,7 @@ extern "C" size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d) {
     const HaloPlan h = halo_plan(d);
     if (h.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h.grid * h.wk);
   }
-  if ((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23) {
+  if ((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23 || d->tile == 29) {
     const Halo9Plan h9 = halo9_plan(d);
     if (h9.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h9.splits * h9.wk);
   }
@@ -1127,7 +1333,7 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     }
     QEA_REQUIRE(d->tile == 0, "qea_conv_wgrad: tile 6 (LDS-halo) needs a 3x3 pad-1 stride-1 conv with R,C in {32,64}, PW %% 32 == 0");
   }
-  if ((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23) {
+  if ((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23 || d->tile == 29) {
     const Halo9Plan h9 = halo9_plan(d);
     if (h9.ok) {
       const size_t slab = (size_t)d->R * 9 * d->C;

@@ -227,7 +227,7 @@ def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride
                        stride_h=stride[0], stride_w=stride[1], ldp=ldp, ldq=ldq, accumulate=int(accumulate),
                        splits=splits, tile=tile)
     nine_tap = (KH == 3 and KW == 3 and pad == (1, 1) and stride == (1, 1) and PH == QH and PW == QW and R % 32 == 0 and Cc % 32 == 0
-                and (PW % 32 == 0 or PW == 16) and tile in (0, 23))
+                and (PW % 32 == 0 or PW == 16) and tile in (0, 23, 29))
     generic_split = tile in (20, 21, 22) or (tile == 0 and ((R >= 128 and Cc >= 128) or (R >= 128 and Cc == 64) or (R == 64 and Cc >= 128)))
     if SPLIT_F16["on"] and (nine_tap or generic_split) and mfma_mode() != "f32":
         if p_amax is None:

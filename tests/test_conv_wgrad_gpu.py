@@ -79,11 +79,13 @@ def test_wgrad_linear():
                                             (2, 16, 64, 64, 128), (1, 4, 32, 512, 512), (9, 4, 16, 256, 256),
                                             (3, 32, 128, 32, 32), (2, 32, 128, 64, 32), (2, 16, 64, 32, 64), (3, 8, 16, 96, 32), (2, 8, 32, 32, 96)])
 @pytest.mark.parametrize("splits", [0, 1, 3])
-def test_wgrad_nine_tap_split_bf16(B, H, W, Cin, Cout, splits):
-    """tile 23 = wgrad_halo9_bf3_kernel: a workgroup accumulates all nine taps of a 64x64 (or 32-wide) channel block from ONE staged
+@pytest.mark.parametrize("tile", [23, 29])
+def test_wgrad_nine_tap_split_bf16(B, H, W, Cin, Cout, splits, tile):
+    """tile 23 with 64-channel blocks in the fp16 form = wgrad_halo9_spec_kernel (round 4: four MFMA waves + four staging waves per
+    workgroup, two LDS buffers); tile 29 (and the 32-wide blocks / the bf16 form under tile 23) = wgrad_halo9_bf3_kernel: a workgroup accumulates all nine taps of a 64x64 (or 32-wide) channel block from ONE staged
     dY tile + X halo (split once) instead of gathering and splitting both operands per tap; 32- and 16-pixel-wide tiles,
     image borders, pixel splits (order-fixed slab reduction), accumulate; against torch-CPU autograd in fp64."""
-    _conv_case(B, H, W, Cin, Cout, tile=23, splits=splits, seed=B * 100 + H, accumulate=(splits == 3))
+    _conv_case(B, H, W, Cin, Cout, tile=tile, splits=splits, seed=B * 100 + H, accumulate=(splits == 3))
 
 
 def test_wgrad_nine_tap_bit_reproducible_and_default():
@@ -98,3 +100,10 @@ def test_wgrad_nine_tap_bit_reproducible_and_default():
         ops.conv_wgrad(dy, x, dw, B=Bn, PH=Hh, PW=Ww, QH=Hh, QW=Ww, R=Co, Cc=Ci, KH=3, KW=3, pad=(1, 1), ldp=Co, ldq=Ci, tile=tile)
         outs.append(dw.clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # the round-3 form of the same kernel (every wave stages): other slabs, same products — equal to fp32 rounding, and reproducible
+    for tile in (29, 29):
+        dw = torch.empty(Co, 3, 3, Ci, device="cuda")
+        ops.conv_wgrad(dy, x, dw, B=Bn, PH=Hh, PW=Ww, QH=Hh, QW=Ww, R=Co, Cc=Ci, KH=3, KW=3, pad=(1, 1), ldp=Co, ldq=Ci, tile=tile)
+        outs.append(dw.clone())
+    assert torch.equal(outs[3], outs[4])
+    assert (outs[3] - outs[0]).abs().max().item() <= 2e-6 * outs[0].abs().max().item()

@@ -60,7 +60,9 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 #define V_NB(n) ((n) << 16)
 // V_UNSW: 16x16x32 form with the pixels as the A operand (accumulator: column = channel on the lane, rows = 4 consecutive pixels)
 // V_INSPLIT: the fp16 split of the prefetched halo is done IN the MFMA loop (one float4 per step, in place), the stage phase only writes LDS
-enum { V_UNSW = 1024, V_INSPLIT = 2048, V_ZP = 512, V_ROT = 1, V_M16 = 2, V_NOSTAGE = 4, V_NOB = 8, V_NOEPI = 16, V_STAMP = 32, V_EPI4 = 64, V_NOA = 128, V_WG3 = 256 };
+enum { V_UNSW = 1024, V_INSPLIT = 2048, V_ZP = 512, V_ROT = 1, V_M16 = 2, V_NOSTAGE = 4, V_NOB = 8, V_NOEPI = 16, V_STAMP = 32, V_EPI4 = 64, V_NOA = 128, V_WG3 = 256, V_ROTP = 4096 };
+// V_ROTP (16x16x32 form): slots of pixel row p rotated by p, not p >> 1 — conflict-free for ds_read_b128's 16-lane groups by the guide's bank model
+// (the p >> 1 rotation puts lanes {12..15} and {24..27} of a group on the same banks), and only 8 table registers
 
 constexpr int CIN = 64, COUT = 128, TH = 4, TW = 32, HWD = 34, HH = 6, HP = HH * HWD, WN = 4, MI = 4, KS = 4, PLANE = HP * CIN;
 constexpr int PLANE_B = PLANE * 2;
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VAR & V_WG
     it.y0 = ty * TH;
     return it;
   };
-  auto swz = [](int p, int slot) { return ROT ? ((slot + (p >> 1)) & 7) : (slot ^ ((p >> 1) & 7)); };
+  constexpr bool ROTP = (VAR & V_ROTP) != 0;
+  auto swz = [](int p, int slot) { return ROTP ? ((slot + p) & 7) : ROT ? ((slot + (p >> 1)) & 7) : (slot ^ ((p >> 1) & 7)); };
 
   constexpr int C4 = CIN / 4, NLD = (HP * C4 + 255) / 256, QS = 256 / C4;
   f32x4 hv[NLD];
@@ -167,8 +170,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VAR & V_WG
     const int q0 = (px >> 1) + g, q1 = ((px + 1) >> 1) + g;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      T[0][k] = px * (CIN * 2) + (((k + q0) & 7) << 4);
-      T[1][k] = px * (CIN * 2) + (((k + q1) & 7) << 4);
+      T[0][k] = px * (CIN * 2) + (((k + (ROTP ? px + g : q0)) & 7) << 4);
+      T[1][k] = px * (CIN * 2) + (((k + (ROTP ? px + g : q1)) & 7) << 4);
     }
   }
 
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VAR & V_WG
           const int kh = tap / 3, kw = tap % 3;
           const int i = g / 2, xh = g % 2;
           const int c = (i + kh) * HWD + kw + xh * 16;
-          const char* src = reinterpret_cast<const char*>(As) + T[c & 1][(ks * 4 + (c >> 1)) & 7] + c * (CIN * 2);
+          const char* src = reinterpret_cast<const char*>(As) + (ROTP ? T[0][(ks * 4 + c) & 7] : T[c & 1][(ks * 4 + (c >> 1)) & 7]) + c * (CIN * 2);
           a[0] = *reinterpret_cast<const f16x8*>(src);
           a[1] = *reinterpret_cast<const f16x8*>(src + PLANE_B);
         };
@@ -607,6 +610,10 @@ int main(int argc, char** argv) {
       VARIANT("rot+zp+epi4", V_ROT | V_ZP | V_EPI4),
       VARIANT("m16", V_ROT | V_M16),
       VARIANT("m16+zp", V_ROT | V_M16 | V_ZP),
+      VARIANT("m16+zp rotp", V_ROT | V_M16 | V_ZP | V_ROTP),
+      VARIANT("m16+zp rotp nb3", V_ROT | V_M16 | V_ZP | V_ROTP | V_NB(3)),
+      VARIANT("m16+zp nb3", V_ROT | V_M16 | V_ZP | V_NB(3)),
+      VARIANT("m16+zp rotp nb6", V_ROT | V_M16 | V_ZP | V_ROTP | V_NB(6)),
       VARIANT("m16+zp unsw", V_ROT | V_M16 | V_ZP | V_UNSW),
       VARIANT("m16+zp insplit", V_ROT | V_M16 | V_ZP | V_INSPLIT),
       VARIANT("m16+zp unsw insplit", V_ROT | V_M16 | V_ZP | V_UNSW | V_INSPLIT),
