@@ -1418,9 +1418,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_bf3_wg
 // on the same tile at equal cycles per flop (MI355X_MICROARCH.md, DVFS give-back item 7): 420 -> 454 / 437 -> 470 / 352 -> 365
 // TFLOP/s on 256->256 / 512->512 / 64->128 channels.  Same tiling as above (TH x 32 pixel tile, one wave = MI rows x 32 output
 // channels = MI * 2 pixel groups x 2 channel groups of 16 x 16 accumulator tiles), same LDS image and staging, but:
-//  * the 16-byte slots of pixel row p are ROTATED by p >> 1 (slot + (p >> 1)) & 7 instead of XOR-ed: a rotation commutes with the
-//    compile-time pixel offset of a tap, so all fragment addresses of a lane are 16 table registers (8 rotations x the parity of
-//    the offset) + an immediate — no address arithmetic in the loop and no opaque thread-id trick (180 vs 207 registers);
+//  * the 16-byte slots of pixel row p are ROTATED by p, (slot + p) & 7, instead of XOR-ed: a rotation commutes with the
+//    compile-time pixel offset of a tap, so all fragment addresses of a lane are 8 table registers + an immediate — no address
+//    arithmetic in the loop and no opaque thread-id trick.  (The first form rotated by p >> 1: 16 table registers and, by the guide's
+//    16-lane ds_read_b128 groups {0-3, 12-15, 20-27}, a two-way conflict between lanes 12-15 and 24-27 — PMC 0.135 conflict cycles
+//    per wave cycle, 0.0 with this one: profiles/r04_halo_lab_pmc.json);
 //  * out-of-image halo pixels are LOADED from a zero-filled 16 bytes instead of selected to zero behind the load: the select made
 //    hipcc wait for the whole gather right after issuing it;
 //  * filter planes in the order [n-block][chunk][step = tap * 2 + ks][plane][16-channel group][lane][8] (qea_pack_frag_planes_f16
@@ -1445,7 +1447,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_m16_wg
   constexpr int IPX = SMALL ? 32 / IMW : 1, IPY = SMALL ? TH / IMH : 1;
   constexpr int TW = 32, HW_ = SMALL ? IPX * (IMW + 2) : TW + 2, HH = SMALL ? TH + 1 : TH + 2, HP = HH * HW_;
   static_assert(!SMALL || COUT == 128, "small-image tiles: one wave row");
-  static_assert(HW_ % 2 == 0, "the rotation table needs an even halo row");
   constexpr int WN = COUT / 32, WM = 4 / WN, MI = TH / WM;
   constexpr int NG = COUT / 16;                           // 16-channel groups per n-block
   constexpr int PLANE = HP * CIN, PLANE_B = PLANE * 2;
@@ -1480,7 +1481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_m16_wg
     it.y0 = ty * TH;
     return it;
   };
-  auto rot = [](int p, int slot) { return (slot + (p >> 1)) & 7; };
+  auto rot = [](int p, int slot) { return (slot + p) & 7; };
 
   constexpr int C4 = CIN / 4, NLD = (HP * C4 + 255) / 256, QS = 256 / C4;
   f32x4 hv[NLD];
@@ -1535,18 +1536,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_m16_wg
   const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
   const int p16 = lane_ & 15, g4 = lane_ >> 4;
   const int wm = wave_ / WN, wn = wave_ % WN;
-  // byte offset of (pixel = W0 + lpx + c, slot = ks * 4 + g4) = T[c & 1][(ks * 4 + (c >> 1)) & 7] + c * 128, c a compile-time pixel offset,
-  // W0 = this wave's first tile row (even pixel count), lpx = the lane's pixel inside the group (small 8-pixel images: + the zero columns)
-  int T[2][8];
+  // byte offset of (pixel = W0 + lpx + c, slot = ks * 4 + g4) = T[(ks * 4 + c) & 7] + c * 128, c a compile-time pixel offset,
+  // W0 = this wave's first tile row, lpx = the lane's pixel inside the group (small 8-pixel images: + the zero columns)
+  int T[8];
   {
     const int lpx = (IMW == 8) ? p16 + 2 * (p16 >> 3) : p16;
     const int W0 = SMALL ? 0 : wm * MI * HW_;
-    const int q0 = (lpx >> 1) + g4 + (W0 >> 1), q1 = ((lpx + 1) >> 1) + g4 + (W0 >> 1);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      T[0][k] = (lpx + W0) * (CIN * 2) + (((k + q0) & 7) << 4);
-      T[1][k] = (lpx + W0) * (CIN * 2) + (((k + q1) & 7) << 4);
-    }
+    for (int k = 0; k < 8; ++k) T[k] = (lpx + W0) * (CIN * 2) + (((k + g4 + lpx + W0) & 7) << 4);
   }
 
   f16x8 bq[2][2][2];                                      // [buffer][channel group of the wave][plane]
@@ -1598,7 +1595,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(halo_m16_wg
         } else {
           c = (i + kh) * HW_ + kw + xh * 16;
         }
-        const char* src = reinterpret_cast<const char*>(As) + T[c & 1][(ks * 4 + (c >> 1)) & 7] + c * (CIN * 2);
+        const char* src = reinterpret_cast<const char*>(As) + T[(ks * 4 + c) & 7] + c * (CIN * 2);
         a[0] = *reinterpret_cast<const f16x8*>(src);
         a[1] = *reinterpret_cast<const f16x8*>(src + PLANE_B);
       };

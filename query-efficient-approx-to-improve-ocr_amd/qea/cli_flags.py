@@ -56,6 +56,10 @@ FLAGS = [
                                                       "The N documents go through the cleaner as ONE batch with per-document BatchNorm statistics "
                                                       "and through the CRNN of Phase B as one batch; forward values equal N sequential passes, the "
                                                       "gradients of the N documents accumulate into one Adam step"), "p"),
+    ("--graph", dict(action="store_true", help="[new] replay Phase B (cleaner -> CRNN -> CTC + MSE -> backward -> Adam) as ONE hipGraph per "
+                                               "(batch size, width): at the reference's batch sizes (tens of strips) a step is bound by the host "
+                                               "time of ~600 launches, which the replay removes; the first two steps of a shape run eagerly, "
+                                               "single-process runs only"), "a"),
     ("--no_rebalance_topk", dict(action="store_true", help="[new] data-parallel runs only: process every global TopKCER winner on the rank "
                                                            "that owns it instead of dealing the winners out in equal slices (one all-reduce of "
                                                            "k x 16 KB images); always so with --inner_limit_skip (label histories stay with the owner)"), "a"),

@@ -37,3 +37,75 @@ class GraphedStep:
         from . import ops
         ops.bump_weight_epoch()
         return self.out
+
+
+class PhaseBGraphs:
+    """Phase B of the area trainer (train_nn_area.py:273-287) as one hipGraph per (batch size, width, target-length cap).
+
+    trainer: a TrainerCore on the HIP backend whose optimisers were built with capturable=True.  The first `eager_steps` steps of
+    a shape run eagerly (they create every lazily allocated buffer: workspaces, the weight-gradient side stream, Adam's flat
+    moments and device step counter); the next one is captured and every later one replays it.  Inputs are copied into static
+    buffers (images on the device already; targets padded to batch x cap int32), outputs (loss, log-probs, cleaned images) are static
+    tensors valid until the next replay.  A batch whose longest label exceeds the cap of its graph gets a new graph with a
+    larger cap."""
+
+    def __init__(self, trainer, eager_steps=2):
+        self.t = trainer
+        self.eager_steps = eager_steps
+        self.seen = {}
+        self.graphs = {}
+
+    def _cap(self, labels):
+        need = max(1, max(len(l) for l in labels))
+        return ((need + 7) // 8) * 8
+
+    def step(self, X, labels):
+        """Returns (loss, scores, img_preds) of one Phase-B step on X [B,1,H,W] (device) with ground-truth `labels`, or None when the
+        step has to run eagerly (shape still warming up)."""
+        t = self.t
+        B, _, Hh, W = X.shape
+        shape = (B, Hh, W)
+        n = self.seen.get(shape, 0)
+        self.seen[shape] = n + 1
+        if n < self.eager_steps:
+            return None
+        cap = self._cap(labels)
+        key = None
+        for k in self.graphs:
+            if k[:3] == shape and k[3] >= cap and (key is None or k[3] < key[3]):
+                key = k
+        if key is None:
+            key = shape + (cap,)
+            self.graphs[key] = self._capture(X, key)
+        g = self.graphs[key]
+        g["X"].copy_(X)
+        L = key[3]
+        y = torch.zeros(B * L, dtype=torch.int32)
+        ysz = torch.tensor([len(l) for l in labels], dtype=torch.int32)
+        flat = [t.char_to_index[c] for c in "".join(labels)]
+        y[:len(flat)] = torch.tensor(flat, dtype=torch.int32)
+        g["y"].copy_(y, non_blocking=False)
+        g["ysz"].copy_(ysz, non_blocking=False)
+        return g["step"]()
+
+    def _capture(self, X, key):
+        t = self.t
+        B, Hh, W, L = key
+        dev = X.device
+        st = {"X": torch.empty_like(X), "y": torch.zeros(B * L, dtype=torch.int32, device=dev),
+              "ysz": torch.ones(B, dtype=torch.int32, device=dev)}
+        ctc = type(t.primary_loss_fn)()
+        ctc.max_target_length = L
+
+        def fn():
+            t._set_phase_b()
+            img = t.prep_model(st["X"])
+            scores = t.crnn_model(img)
+            pred = torch.full((B,), scores.shape[0], dtype=torch.int32, device=dev)
+            loss = ctc(scores, st["y"], pred, st["ysz"]) + t.secondary_loss_fn(img, torch.ones_like(img)) * t.sec_loss_scalar
+            loss.backward()
+            t._step_prep()
+            return loss.detach(), scores.detach(), img.detach()
+
+        st["step"] = GraphedStep(fn, warmup=0)
+        return st

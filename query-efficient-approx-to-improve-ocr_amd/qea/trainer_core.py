@@ -128,8 +128,16 @@ class TrainerCore:
         self.primary_loss_fn = B.CTCLoss().to(self.device)
         self.primary_loss_fn_sample_wise = B.CTCLoss(reduction="none").to(self.device)
         self.secondary_loss_fn = torch.nn.MSELoss().to(self.device)
-        self.optimizer_crnn = B.Adam(self.crnn_model.parameters(), lr=self.lr_crnn, weight_decay=weight_decay)
-        self.optimizer_prep = B.Adam(self.prep_model.parameters(), lr=self.lr_prep, weight_decay=weight_decay)
+        # [new] --graph: Phase B replayed as a hipGraph (qea.graph.PhaseBGraphs); needs Adam's step count on the device
+        self.phase_b_graphs = None
+        adam_kw = {}
+        if getattr(args, "graph", False) and self.world == 1 and self.device.type == "cuda" and self.backend.gpu_jitter:
+            adam_kw = {"capturable": True}
+        self.optimizer_crnn = B.Adam(self.crnn_model.parameters(), lr=self.lr_crnn, weight_decay=weight_decay, **adam_kw)
+        self.optimizer_prep = B.Adam(self.prep_model.parameters(), lr=self.lr_prep, weight_decay=weight_decay, **adam_kw)
+        if adam_kw:
+            from qea.graph import PhaseBGraphs
+            self.phase_b_graphs = PhaseBGraphs(self)
 
     def _make_sampler(self, needs_cers):
         from selection_utils import datasampler_factory

@@ -155,12 +155,16 @@ class TrainNNPrep(TrainerCore):
                         (loss * share if share != 1.0 else loss).backward()   # the last replica only, as the reference (:269-271)
                         self._step_crnn()
                 # ---------------- Phase B ----------------
-                self._set_phase_b()
-                img_preds = self.prep_model(X_var)
-                scores, y, pred_size, y_size = self._call_model(img_preds, labels)
-                loss = self._get_loss(scores, y, pred_size, y_size, img_preds)
-                loss.backward()
-                self._step_prep()
+                replayed = self.phase_b_graphs.step(X_var, labels) if self.phase_b_graphs is not None else None
+                if replayed is not None:                         # [new] --graph: the same step as one hipGraph replay
+                    loss, scores, img_preds = replayed
+                else:
+                    self._set_phase_b()
+                    img_preds = self.prep_model(X_var)
+                    scores, y, pred_size, y_size = self._call_model(img_preds, labels)
+                    loss = self._get_loss(scores, y, pred_size, y_size, img_preds)
+                    loss.backward()
+                    self._step_prep()
                 self._update_cers(scores, labels, names)
                 training_loss += loss.item()
                 if step % 100 == 0:

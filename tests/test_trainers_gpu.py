@@ -93,6 +93,35 @@ def test_patch_trainer_hip_docs_per_step(tmp_path):
     assert set(t.sampler.all_cers.keys()) == set(names) and all(len(v) == 1 for v in t.sampler.all_cers.values())
 
 
+def test_area_trainer_graph_replays_phase_b(tmp_path):
+    """[new] --graph: Phase B of the area trainer as one hipGraph per shape (two eager steps, then capture, then replays) is the
+    same training as the eager loop: same losses step by step, same weights after six steps."""
+    from datasets.synthetic import SyntheticTextAreas
+    from train_nn_area import TrainNNPrep
+    res = {}
+    for flag in (False, True):
+        torch.manual_seed(0)
+        tr = SyntheticTextAreas(48, seed=1, include_name=True, include_index=True)
+        args = _args("a", tmp_path / f"exp{int(flag)}", batch_size=8, inner_limit=0, graph=flag)
+        t = TrainNNPrep(args, train_set=tr, val_set=SyntheticTextAreas(8, seed=2, include_name=True))
+        assert (t.phase_b_graphs is not None) == flag
+        losses = []
+        if flag:
+            orig = t.phase_b_graphs.step
+            def spy(X, labels, orig=orig, losses=losses):
+                r = orig(X, labels)
+                losses.append(None if r is None else float(r[0].item()))
+                return r
+            t.phase_b_graphs.step = spy
+        t.train()
+        res[flag] = (torch.cat([p.detach().flatten().clone() for p in t.prep_model.parameters()]), losses)
+        if flag:
+            assert len(losses) == 6 and losses[0] is None and losses[1] is None and all(l is not None and l == l for l in losses[2:])
+            assert len(t.phase_b_graphs.graphs) >= 1
+    d = (res[True][0] - res[False][0]).abs().max().item()
+    assert d <= 2e-6, d                                        # Adam moves a weight by ~lr = 5e-5 per step
+
+
 @pytest.mark.parametrize("method", ["levenshtein", "self_attention"])
 def test_area_trainer_label_history_weightgens(tmp_path, method):
     """--inner_limit_skip with the non-decaying weight generators: sample-wise CTC (reduction='none') on the HIP path

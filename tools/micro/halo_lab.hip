@@ -60,7 +60,8 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 #define V_NB(n) ((n) << 16)
 // V_UNSW: 16x16x32 form with the pixels as the A operand (accumulator: column = channel on the lane, rows = 4 consecutive pixels)
 // V_INSPLIT: the fp16 split of the prefetched halo is done IN the MFMA loop (one float4 per step, in place), the stage phase only writes LDS
-enum { V_UNSW = 1024, V_INSPLIT = 2048, V_ZP = 512, V_ROT = 1, V_M16 = 2, V_NOSTAGE = 4, V_NOB = 8, V_NOEPI = 16, V_STAMP = 32, V_EPI4 = 64, V_NOA = 128, V_WG3 = 256, V_ROTP = 4096 };
+enum { V_UNSW = 1024, V_INSPLIT = 2048, V_ZP = 512, V_ROT = 1, V_M16 = 2, V_NOSTAGE = 4, V_NOB = 8, V_NOEPI = 16, V_STAMP = 32, V_EPI4 = 64, V_NOA = 128, V_WG3 = 256, V_ROTP = 4096, V_NODEEP = 8192 };
+// V_NODEEP: with more than two filter buffers, keep the halo gather where the two-buffer form has it (behind the barrier, before the loop)
 // V_ROTP (16x16x32 form): slots of pixel row p rotated by p, not p >> 1 — conflict-free for ds_read_b128's 16-lane groups by the guide's bank model
 // (the p >> 1 rotation puts lanes {12..15} and {24..27} of a group on the same banks), and only 8 table registers
 
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VAR & V_WG
   constexpr bool NOEPI = (VAR & V_NOEPI) != 0, STAMP = (VAR & V_STAMP) != 0, EPI4 = (VAR & V_EPI4) != 0, NOA = (VAR & V_NOA) != 0;
   static_assert(!M16 || ROT, "the 16x16x32 form is written on the rotation swizzle");
   constexpr int NB = (VAR >> 16) ? (VAR >> 16) : 2;
-  constexpr bool DEEP = (VAR >> 16) != 0;
+  constexpr bool DEEP = (VAR >> 16) != 0 && (VAR & V_NODEEP) == 0;
   constexpr bool UNSW = (VAR & V_UNSW) != 0, INSPLIT = (VAR & V_INSPLIT) != 0;              // gather issued inside the loop (behind step 0's filter load)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* As = reinterpret_cast<_Float16*>(smem);
@@ -613,6 +614,7 @@ int main(int argc, char** argv) {
       VARIANT("m16+zp rotp", V_ROT | V_M16 | V_ZP | V_ROTP),
       VARIANT("m16+zp rotp nb3", V_ROT | V_M16 | V_ZP | V_ROTP | V_NB(3)),
       VARIANT("m16+zp nb3", V_ROT | V_M16 | V_ZP | V_NB(3)),
+      VARIANT("m16+zp rotp nb3 nodeep", V_ROT | V_M16 | V_ZP | V_ROTP | V_NB(3) | V_NODEEP),
       VARIANT("m16+zp rotp nb6", V_ROT | V_M16 | V_ZP | V_ROTP | V_NB(6)),
       VARIANT("m16+zp unsw", V_ROT | V_M16 | V_ZP | V_UNSW),
       VARIANT("m16+zp insplit", V_ROT | V_M16 | V_ZP | V_INSPLIT),
