@@ -150,7 +150,7 @@ def cpu_baseline():
             "b128": b128, "b32": b32, "host": host}
 
 
-DOMINANT_KERNEL = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 2, 0, false>"
+DOMINANT_KERNEL = "conv3x3_halo_m16_kernel<128, false, 0, 0, false>"   # (round 4: the 16x16x32 form of the two-way fp16 LDS-halo conv, 64-channel chunks)
 DOMINANT_KERNEL_BF16 = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 3>"
 
 
@@ -430,7 +430,7 @@ def main():
         prof = {k: ops.prof_read(k) for k in (ops.PROF_CONV_IGEMM, ops.PROF_CONV_WGRAD, ops.PROF_LSTM_STEP)}
         for k in list(prof):
             ops.prof_enable(k, False)
-        # the single dominant kernel of the step (rocprofv3 lists it as conv3x3_halo_bf3_kernel<64, 128, 4, false>)
+        # the single dominant kernel of the step (rocprofv3 lists it as conv3x3_halo_m16_kernel<128, false, 0, 0, false>; bf16 mode: conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 3>)
         prof["dominant"] = ops.prof_read_tagged(ops.PROF_CONV_IGEMM, ops.prof_tag_halo_bf3(64, 128, False, f16=ops.mfma_mode() == "split_f16"))
         ops.set_overlap(overlap0)
         return prof, d, overlap0

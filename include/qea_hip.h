@@ -279,6 +279,17 @@ int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t lda, const
                const float* relu_shift, const float* y, int32_t ldy, int64_t M, int32_t C, const float* gamma, const float* mean, const float* invstd, const double* stat64,
                int32_t training, float* dgamma, float* dbeta, int32_t accumulate_param_grads, float* dy,
                int32_t lddy, void* workspace, size_t workspace_bytes, float* absmax_out, void* stream);
+/* ABI v8 (additive).  qea_maxpool_bwd(accumulate) + qea_bn_bwd in one: the BatchNorm(+ReLU) backward of a block whose output went to a
+ * 2 x kw max-pool (kw in {1, 2}; model_unet.py:52-59 pool1-4, model_crnn.py:53-54 the (2,1) pools) and possibly to a skip connection.
+ * da [B*H*W][ldda] = the gradient from the skip path (NULL: none), dpool [B*(H/2)*(W/kw)][lddp] = the gradient of the pooled tensor;
+ * the pool's winners and the ReLU mask are recomputed from y with relu_scale / relu_shift (required), so neither the activation nor
+ * the summed gradient is read or written.  Same values as the two calls (the fp64 reductions visit the pixels in another order).
+ * Workspace: qea_colreduce_workspace_bytes(B*H*W, C). */
+int qea_bn_bwd_pool(const float* da, int32_t ldda, const float* dpool, int32_t lddp, int32_t kw, const float* relu_scale,
+                    const float* relu_shift, const float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C, const float* gamma,
+                    const float* mean, const float* invstd, const double* stat64, int32_t training, float* dgamma, float* dbeta,
+                    int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace, size_t workspace_bytes, float* absmax_out,
+                    void* stream);
 /* ABI v7 (additive).  qea_bn_bwd with the two per-channel reductions taken from `partials` [blocks (+ 256 scratch rows)][C][2] fp64, as
  * written by the producing input-gradient launch (qea_conv_desc.bst_y), instead of a pass over da and y: finalize + the elementwise
  * pass only.  stat64 and relu_scale / relu_shift are required (what the producer used); workspace: 3 * C doubles. */

@@ -300,6 +300,122 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(const float* 
   qea_amax_commit_block(am, amax);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4 (ABI v8): the max-pool backward INSIDE the BatchNorm(+ReLU) backward that follows it.  A block's output a = relu(bn(y)) goes to
+// a kh x kw max-pool (kh = 2, kw in {1, 2}; model_unet.py:52-59, model_crnn.py:50-54) and, in the UNet, to a skip connection: the
+// gradient that reaches the BatchNorm is da = dskip + maxpool_bwd(dpool).  qea_maxpool_bwd made that sum in a pass of its own (read a,
+// read dpool, read + write dskip: 3.25 tensor passes); here both kernels of the BatchNorm backward rebuild it per WINDOW: the four
+// (two) activations of a window are recomputed from y with the forward's own fused multiply-add (bn_affine + max(., 0): bit for bit
+// what bn_apply stored and what the pool saw), the winner is the first maximum in (kh, kw) scan order, NaN wins (PyTorch's rule, as
+// maxpool_fwd / maxpool_bwd), and dz = relu'(a) * (da + [winner] dpool).  A thread keeps one float4 channel column and walks windows.
+// Values: identical to qea_maxpool_bwd(accumulate) followed by qea_bn_bwd (same fp32 add, same mask); the two fp64 reductions visit the
+// pixels in another order (equal to ~1e-16 relative).
+// ---------------------------------------------------------------------------------------------
+template <int KW, bool APPLY>
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_pool_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ dpool, int lddp,
+                                                                   const float* __restrict__ y, int ldy, float* __restrict__ dy, int lddy, int B, int H,
+                                                                   int W, int C, const float* __restrict__ msc, const float* __restrict__ msh,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const double* __restrict__ stat64, const double* __restrict__ k0,
+                                                                   const double* __restrict__ k1, const double* __restrict__ k2,
+                                                                   int win_per_block, int rt_n, double* __restrict__ ws, float* __restrict__ amax) {
+  extern __shared__ __attribute__((aligned(16))) double sred[];  // reduction form: [rt_n][C][2]
+  constexpr int NP = 2 * KW;
+  const int cols = C / 4;
+  const int ct = threadIdx.x % cols, rt = threadIdx.x / cols;
+  const int OH = H / 2, OW = W / KW;
+  const long long NWIN = (long long)B * OH * OW;
+  const bool idle = rt >= rt_n;
+  float am = 0.f;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  double mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0}, c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(msc + ct * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(msh + ct * 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (APPLY) {
+      c0[k] = k0[ct * 4 + k];
+      c1[k] = k1[ct * 4 + k];
+      c2[k] = k2[ct * 4 + k];
+    } else {
+      mu[k] = stat64 ? stat64[ct * 4 + k] : (double)mean[ct * 4 + k];
+      is[k] = stat64 ? stat64[C + ct * 4 + k] : (double)invstd[ct * 4 + k];
+    }
+  }
+  const long long w0 = (long long)blockIdx.x * win_per_block;
+  long long w1 = w0 + win_per_block;
+  if (w1 > NWIN) w1 = NWIN;
+  for (long long wi = idle ? w1 : w0 + rt; wi < w1; wi += rt_n) {
+    const int ow = (int)(wi % OW);
+    const int oh = (int)((wi / OW) % OH);
+    const int b = (int)(wi / ((long long)OW * OH));
+    const long long r00 = ((long long)b * H + 2 * oh) * W + (long long)ow * KW;
+    long long rows[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) rows[j] = r00 + (j / KW) * (long long)W + (j % KW);
+    f32x4 yv[NP], dv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      yv[j] = *reinterpret_cast<const f32x4*>(y + rows[j] * ldy + ct * 4);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      dv[j] = da ? *reinterpret_cast<const f32x4*>(da + rows[j] * ldda + ct * 4) : zero;
+    }
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dpool + wi * lddp + ct * 4);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {0, 0, 0, 0};
+    f32x4 av[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = fmaxf(bn_affine(yv[j][k], sc[k], sh[k]), 0.f);
+        av[j][k] = v;
+        if (v > m[k] || v != v) {
+          m[k] = v;
+          arg[k] = j;
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = (arg[k] == j ? g[k] : 0.f) + dv[j][k];      // (qea_maxpool_bwd's accumulate: routed gradient + what the skip path left)
+        d = av[j][k] > 0.f ? d : 0.f;
+        if (APPLY) {
+          o[k] = (float)(c0[k] * (double)d + (c1[k] * (double)yv[j][k] + c2[k]));
+          am = qea_amax_acc(am, o[k]);
+        } else {
+          s0[k] += (double)d;
+          s1[k] += (double)d * (((double)yv[j][k] - mu[k]) * is[k]);
+        }
+      }
+      if (APPLY) *reinterpret_cast<f32x4*>(dy + rows[j] * lddy + ct * 4) = o;
+    }
+  }
+  if constexpr (APPLY) {
+    qea_amax_commit_block(am, amax);
+  } else {
+    if (!idle) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sred[((size_t)rt * C + ct * 4 + k) * 2 + 0] = s0[k];
+        sred[((size_t)rt * C + ct * 4 + k) * 2 + 1] = s1[k];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      double t0 = 0, t1 = 0;
+      for (int r = 0; r < rt_n; ++r) {
+        t0 += sred[((size_t)r * C + c) * 2 + 0];
+        t1 += sred[((size_t)r * C + c) * 2 + 1];
+      }
+      ws[((size_t)blockIdx.x * C + c) * 2 + 0] = t0;
+      ws[((size_t)blockIdx.x * C + c) * 2 + 1] = t1;
+    }
+  }
+}
+
 // max-pool with window == stride (2x2 or 2x1), PyTorch tie rule: first maximum in (kh,kw) scan order
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C,
                                    int kh, int kw, float* __restrict__ amax) {
@@ -596,6 +712,46 @@ extern "C" int qea_bn_bwd(const float* da, int32_t ldda, const float* a, int32_t
   agrid = (M + arows - 1) / arows;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)agrid), dim3(RED_THREADS), 0, s, da, ldda, a, lda, y, ldy, dy, lddy, (long long)M,
                      C, relu_scale, relu_shift, (const double*)k0, (const double*)k1, (const double*)k2, arows, g.rt, absmax_out);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+extern "C" int qea_bn_bwd_pool(const float* da, int32_t ldda, const float* dpool, int32_t lddp, int32_t kw, const float* relu_scale,
+                               const float* relu_shift, const float* y, int32_t ldy, int32_t B, int32_t H, int32_t W, int32_t C,
+                               const float* gamma, const float* mean, const float* invstd, const double* stat64, int32_t training, float* dgamma,
+                               float* dbeta, int32_t accumulate_param_grads, float* dy, int32_t lddy, void* workspace, size_t workspace_bytes,
+                               float* absmax_out, void* stream) {
+  QEA_REQUIRE(dpool && y && mean && invstd && dy && relu_scale && relu_shift, "qea_bn_bwd_pool: null pointer (relu_scale / relu_shift are required)");
+  QEA_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && (kw == 1 || kw == 2) && W % kw == 0, "qea_bn_bwd_pool: 2 x kw windows, kw in {1, 2}, H and W multiples");
+  const long long M = (long long)B * H * W;
+  const long long NWIN = M / (2 * kw);
+  const ColGeom g = col_geom(NWIN, C);
+  int rc = check_nc("qea_bn_bwd_pool", M, C, workspace_bytes, workspace, g);
+  if (rc) return rc;
+  QEA_REQUIRE(workspace_bytes >= qea_colreduce_workspace_bytes(M, C), "qea_bn_bwd_pool: workspace too small (qea_colreduce_workspace_bytes(B * H * W, C))");
+  QEA_REQUIRE(ldy % 4 == 0 && lddy % 4 == 0 && lddp % 4 == 0 && (!da || ldda % 4 == 0), "qea_bn_bwd_pool: strides must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  double* ws = (double*)workspace;
+  // (the constants sit behind the partial rows of qea_bn_bwd's geometry for M rows, which has at least as many blocks)
+  const ColGeom gm = col_geom(M, C);
+  double* k0 = ws + (size_t)(gm.grid > g.grid ? gm.grid : g.grid) * C * 2;
+  double* k1 = k0 + C;
+  double* k2 = k1 + C;
+  const size_t lds = (size_t)g.rt * C * 2 * sizeof(double);
+  auto red = kw == 2 ? bn_bwd_pool_kernel<2, false> : bn_bwd_pool_kernel<1, false>;
+  hipLaunchKernelGGL(red, dim3(g.grid), dim3(RED_THREADS), lds, s, da, ldda, dpool, lddp, y, ldy, (float*)nullptr, 0, B, H, W, C, relu_scale, relu_shift,
+                     mean, invstd, stat64, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, g.rows_per_block, g.rt, ws,
+                     (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(qea_cdiv(C, 4)), dim3(256), 0, s, (const double*)ws, g.grid, C, M, gamma, mean, invstd, stat64, training,
+                     dgamma, dbeta, accumulate_param_grads, k0, k1, k2);
+  long long agrid = (NWIN + (long long)g.rt * 4 - 1) / ((long long)g.rt * 4);
+  if (agrid > 4096) agrid = 4096;
+  if (agrid < 1) agrid = 1;
+  const int awin = (int)((NWIN + agrid - 1) / agrid);
+  agrid = (NWIN + awin - 1) / awin;
+  auto app = kw == 2 ? bn_bwd_pool_kernel<2, true> : bn_bwd_pool_kernel<1, true>;
+  hipLaunchKernelGGL(app, dim3((unsigned)agrid), dim3(RED_THREADS), 0, s, da, ldda, dpool, lddp, y, ldy, dy, lddy, B, H, W, C, relu_scale, relu_shift, mean,
+                     invstd, stat64, (const double*)k0, (const double*)k1, (const double*)k2, awin, g.rt, (double*)nullptr, absmax_out);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

@@ -22,6 +22,8 @@ HID = 256
 CONVS = (("conv2", 64, 128, True, (2, 2)), ("conv3", 128, 256, True, None), ("conv4", 256, 256, True, (2, 1)))
 
 
+FUSE_POOL_BWD = True  # tests flip this: conv6's (2,1) pool backward inside BatchNorm2's backward (qea_bn_bwd_pool)
+
 class CRNNEngine:
     def __init__(self, module, vocab):
         self.m = module
@@ -297,8 +299,10 @@ class CRNNEngine:
                        w_src=("flipT", P[c + "conv7.weight"]), x_amax=dseq_amax)
         # pool (2,1) backward -> grad of a6 (ReLU handled by bn_bwd's mask)
         h, w = dims["conv6"]
-        da = torch.empty(B * h * w, 512, device=dev)
-        ops.maxpool_bwd(acts["a6"], 512, dp6, 512, da, 512, B, h, w, 512, 2, 1, relu_mask=False)
+        da = None
+        if not FUSE_POOL_BWD:
+            da = torch.empty(B * h * w, 512, device=dev)
+            ops.maxpool_bwd(acts["a6"], 512, dp6, 512, da, 512, B, h, w, 512, 2, 1, relu_mask=False)
         bn_training = ctx["bn_training"]
         amx = ctx.get("amx", {})                                  # forward tensors' abs-max (a replica-group slice keeps its tensor's bound)
         for name, bn, cin, src in (("conv6", "batchnorm2", 512, "a5"), ("conv5", "batchnorm1", 256, "p4")):
@@ -312,6 +316,15 @@ class CRNNEngine:
             for gi in range(NG):
                 sl = slice(gi * Mg, (gi + 1) * Mg)
                 st = acts["st" + k]
+                if da is None:
+                    # conv6's output went through the (2,1) pool only: its backward rides in the two passes of BatchNorm2's (qea_bn_bwd_pool)
+                    Bg = B // NG
+                    psl = slice(gi * Bg * (h // 2) * w, (gi + 1) * Bg * (h // 2) * w)
+                    ops.bn_bwd_pool(None, 0, dp6[psl], 512, 1, acts["y" + k][sl], 512, Bg, h, w, 512, P[c + bn + ".weight"], coef[gi, 0],
+                                    coef[gi, 1], bn_training, G[c + bn + ".weight"] if param_grads else None,
+                                    G[c + bn + ".bias"] if param_grads else None, dy_[sl], 512, accumulate=True,
+                                    stat64=st[gi] if st is not None else None, relu_scale=coef[gi, 2], relu_shift=coef[gi, 3], amax=dy_amax)
+                    continue
                 ops.bn_bwd(da[sl], 512, None, 0, acts["y" + k][sl], 512, Mg, 512, P[c + bn + ".weight"], coef[gi, 0],
                            coef[gi, 1], bn_training, G[c + bn + ".weight"] if param_grads else None,
                            G[c + bn + ".bias"] if param_grads else None, dy_[sl], 512, accumulate=True,

@@ -448,6 +448,16 @@ def bn_bwd(da, ldda, a, lda, y, ldy, M, C_, gamma, mean, invstd, training, dgamm
                                      _ptr(dy), lddy, wp, wn, _ptr(amax), _stream()), "qea_bn_bwd")
 
 
+def bn_bwd_pool(da, ldda, dpool, lddp, kw, y, ldy, B, H, W, C_, gamma, mean, invstd, training, dgamma, dbeta, dy, lddy, accumulate=False,
+                stat64=None, relu_scale=None, relu_shift=None, amax=None):
+    """maxpool_bwd(accumulate into da) + bn_bwd in one (ABI v8): da = the skip path's gradient or None, dpool = the pooled tensor's gradient;
+    winners and ReLU mask are recomputed from y (relu_scale / relu_shift required)."""
+    wp, wn = _colws(B * H * W, C_, y.device)
+    _lib.check(_lib.lib().qea_bn_bwd_pool(_ptr(da), ldda, _ptr(dpool), lddp, kw, _ptr(relu_scale), _ptr(relu_shift), _ptr(y), ldy, B, H, W, C_,
+                                          _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(stat64), int(training), _ptr(dgamma), _ptr(dbeta),
+                                          int(accumulate), _ptr(dy), lddy, wp, wn, _ptr(amax), _stream()), "qea_bn_bwd_pool")
+
+
 def colsum(x, ldx, M, C_, out, accumulate=False):
     wp, wn = _colws(M, C_, x.device)
     _lib.check(_lib.lib().qea_colsum(_ptr(x), ldx, M, C_, _ptr(out), int(accumulate), wp, wn, _stream()), "qea_colsum")

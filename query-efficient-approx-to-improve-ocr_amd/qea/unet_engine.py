@@ -22,6 +22,7 @@ BN_MOMENTUM = 0.1
 FUSE_EVAL_BN = True   # tests flip this to compare the fused inference epilogue with the two-pass form
 FUSE_BN_BWD_SUMS = True   # tests flip this: BatchNorm1's backward reductions from the producing dgrad's epilogue (qea_conv_desc.bst_y)
 FUSE_BN_POOL = True   # tests flip this: the encoder's BatchNorm apply + ReLU and its 2x2 max-pool in one pass (qea_bn_apply_pool)
+FUSE_POOL_BWD = True  # tests flip this: the encoder's pool backward inside the BatchNorm2 backward (qea_bn_bwd_pool), no pass of its own
 
 
 class _Block:
@@ -216,8 +217,15 @@ class UNetEngine:
         pool = ops.amax_pool(dev)
         slot = (lambda: pool.slot()) if pool is not None else (lambda: None)
 
-        def bn_bwd(da, ldda, y, coef, st, i, dy, M, cout, blk, amax=None, partials=None):
-            """BatchNorm(+ReLU) backward of conv i of a block; per statistics group when the forward ran with bn_groups"""
+        def bn_bwd(da, ldda, y, coef, st, i, dy, M, cout, blk, amax=None, partials=None, pooled=None):
+            """BatchNorm(+ReLU) backward of conv i of a block; per statistics group when the forward ran with bn_groups.
+            pooled = (dpool, ld, h, w): the gradient of the block's 2x2-pooled output still has to be routed to the winners and added to
+            da — done inside the two passes of this backward (qea_bn_bwd_pool)."""
+            if pooled is not None:
+                ops.bn_bwd_pool(da, ldda, pooled[0], pooled[1], 2, y, cout, B, pooled[2], pooled[3], cout, P[blk.key(i, "gamma")], coef[0], coef[1],
+                                training, G[blk.key(i, "gamma")], G[blk.key(i, "beta")], dy, cout, accumulate=True, stat64=st,
+                                relu_scale=coef[2], relu_shift=coef[3], amax=amax)
+                return
             if coef.dim() == 2:
                 ops.bn_bwd(da, ldda, None, 0, y, cout, M, cout, P[blk.key(i, "gamma")], coef[0], coef[1], training, G[blk.key(i, "gamma")],
                            G[blk.key(i, "beta")], dy, cout, accumulate=True, stat64=st, relu_scale=coef[2], relu_shift=coef[3], amax=amax,
@@ -232,16 +240,16 @@ class UNetEngine:
 
         last_amax = [None]                                        # abs-max slot of the tensor block_bwd returned last
 
-        def block_bwd(blk, da2, ldda):
+        def block_bwd(blk, da2, ldda, pooled=None):
             """da2: grad w.r.t. the block output (pixel stride ldda).  Returns grad w.r.t. the block input
-            as a fresh [M][cin] tensor, or None for the first encoder block."""
+            as a fresh [M][cin] tensor, or None for the first encoder block.  pooled: see bn_bwd."""
             s = ctx["blocks"][blk.mod]
             h, w, cin, cout = s["h"], s["w"], s["cin"], blk.cout
             M = B * h * w
             dy2 = torch.empty(M, cout, device=dev)
             # ReLU mask recomputed from y with the forward's scale/shift: the activation is not re-read
             dy2_amax, dy1_amax = slot(), slot()
-            bn_bwd(da2, ldda, s["y2"], s["coef2"], s["st2"], 2, dy2, M, cout, blk, dy2_amax)
+            bn_bwd(da2, ldda, s["y2"], s["coef2"], s["st2"], 2, dy2, M, cout, blk, dy2_amax, pooled=pooled)
             w2 = P[blk.key(2, "w")]
             side.run(lambda: ops.conv_wgrad(dy2, s["a1"], G[blk.key(2, "w")], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cout, KH=3, KW=3,
                                             pad=(1, 1), ldp=cout, ldq=cout, accumulate=True, p_amax=dy2_amax, q_amax=s.get("a1_amax")), dy2)
@@ -296,7 +304,11 @@ class UNetEngine:
         for l in (4, 3, 2, 1):
             cat, hh, ww, c = ctx["cats"][l]
             dskip = dcats[l][:, c:]
-            ops.maxpool_bwd(cat[:, c:], 2 * c, dpool, c, dskip, 2 * c, B, hh, ww, c, 2, 2, relu_mask=False, accumulate=True)
-            dpool = block_bwd(self.enc[l - 1], dskip, 2 * c)
+            if FUSE_POOL_BWD and ctx["blocks"][self.enc[l - 1].mod]["coef2"].dim() == 2:
+                # the pool backward rides in the two passes of BatchNorm2's backward: dskip is read, never rewritten
+                dpool = block_bwd(self.enc[l - 1], dskip, 2 * c, pooled=(dpool, c, hh, ww))
+            else:
+                ops.maxpool_bwd(cat[:, c:], 2 * c, dpool, c, dskip, 2 * c, B, hh, ww, c, 2, 2, relu_mask=False, accumulate=True)
+                dpool = block_bwd(self.enc[l - 1], dskip, 2 * c)
         side.join()
         return None

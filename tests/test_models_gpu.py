@@ -567,6 +567,76 @@ def test_crnn_fused_pools_are_bit_identical():
         assert all(torch.equal(u, v) for u, v in zip(*res))
 
 
+def test_pool_backward_inside_the_bn_backward():
+    """qea_bn_bwd_pool (ABI v8): the max-pool backward + the skip path's sum rebuilt per window inside the two passes of the BatchNorm
+    backward (models/model_unet.py:52-59, models/model_crnn.py:53-54 under autograd) against qea_maxpool_bwd(accumulate) followed by
+    qea_bn_bwd: (i) kernel level with ties, an all-negative window and a NaN — dy bit for bit where the per-channel constants agree bit
+    for bit, the parameter gradients to fp64-order noise; (ii) through the whole UNet and CRNN backward with the engines' switch."""
+    from models.model_crnn import CRNN
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea import crnn_engine, ops, unet_engine
+    g = torch.Generator().manual_seed(5)
+    for kw in (2, 1):
+        B, Hh, Ww, Cc = 3, 8, 16, 64
+        y = torch.randn(B, Hh, Ww, Cc, generator=g)
+        y[0, 0, 0:2, :8] = 0.25                                            # a tie inside a window: first in scan order wins
+        y[1, 2:4, 4:6, 8:16] = -3.0                                        # a window whose activations are all zero
+        y[2, 4, 6, 3] = float("nan")
+        y = y.cuda()
+        gamma = (torch.rand(Cc, generator=g) + 0.5).cuda()
+        beta = torch.randn(Cc, generator=g).mul(0.3).cuda()
+        M = B * Hh * Ww
+        coef = torch.empty(4, Cc, device="cuda")
+        st = torch.empty(2, Cc, device="cuda", dtype=torch.float64)
+        rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+        yfin = torch.nan_to_num(y, nan=0.0)
+        ops.bn_train_stats(yfin.view(M, Cc), Cc, M, Cc, gamma, beta, 1e-5, 0.1, rm, rv, coef[0], coef[1], coef[2], coef[3], st)
+        a = torch.empty(M, Cc, device="cuda")
+        ops.bn_apply(y.view(M, Cc), Cc, a, Cc, M, Cc, coef[2], coef[3], relu=True)
+        dskip = torch.randn(M, Cc, generator=g).cuda()
+        dpool = torch.randn(B * (Hh // 2) * (Ww // kw), Cc, generator=g).cuda()
+        outs = []
+        for fused in (False, True):
+            dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+            dy = torch.empty(M, Cc, device="cuda")
+            if fused:
+                ops.bn_bwd_pool(dskip, Cc, dpool, Cc, kw, y.view(M, Cc), Cc, B, Hh, Ww, Cc, gamma, coef[0], coef[1], True, dg, db, dy, Cc,
+                                accumulate=True, stat64=st, relu_scale=coef[2], relu_shift=coef[3])
+            else:
+                da = dskip.clone()
+                ops.maxpool_bwd(a, Cc, dpool, Cc, da, Cc, B, Hh, Ww, Cc, 2, kw, relu_mask=False, accumulate=True)
+                ops.bn_bwd(da, Cc, None, 0, y.view(M, Cc), Cc, M, Cc, gamma, coef[0], coef[1], True, dg, db, dy, Cc, accumulate=True, stat64=st,
+                           relu_scale=coef[2], relu_shift=coef[3])
+            outs.append((dy.cpu(), dg.cpu(), db.cpu()))
+        (dy0, dg0, db0), (dy1, dg1, db1) = outs
+        ok = torch.isfinite(dg0)                                           # (the NaN's channel is NaN in both)
+        assert torch.equal(torch.isfinite(dg0), torch.isfinite(dg1)) and torch.equal(torch.isnan(dy0), torch.isnan(dy1))
+        assert (dg0[ok] - dg1[ok]).abs().max().item() <= 1e-6 * dg0[ok].abs().max().item()
+        assert (db0[ok] - db1[ok]).abs().max().item() <= 1e-6 * db0[ok].abs().max().item()
+        fin = torch.isfinite(dy0)
+        assert (dy0[fin] - dy1[fin]).abs().max().item() <= 1e-6 * dy0[fin].abs().max().item()
+    res = []
+    try:
+        for fuse in (True, False):
+            unet_engine.FUSE_POOL_BWD = crnn_engine.FUSE_POOL_BWD = fuse
+            net = _load(UNet(), mo.unet_state_shapes, 1).train()
+            crnn = _load(CRNN(95, False), mo.crnn_state_shapes, 2).train()
+            x = H.synth_images(6, 31).cuda()
+            out = net(x)
+            lp = crnn(out)
+            (lp * torch.linspace(0.5, 1.5, lp.numel(), device="cuda").view_as(lp)).sum().backward()
+            res.append([p.grad.clone() for p in list(net.parameters()) + list(crnn.parameters())])
+    finally:
+        unet_engine.FUSE_POOL_BWD = crnn_engine.FUSE_POOL_BWD = True
+    worst = 0.0
+    for u, v in zip(*res):
+        den = v.double().norm().item()
+        if den > 0:
+            worst = max(worst, (u.double() - v.double()).norm().item() / den)
+    assert worst <= 2e-6, worst
+
+
 def test_bn_backward_sums_from_the_dgrad_epilogue():
     """qea_conv_desc.bst_y (ABI v7): the two per-channel reductions of BatchNorm1's backward (sum dz, sum dz * xhat with the ReLU mask
     recomputed from the pre-BN tensor; models/model_unet.py:78-109 under autograd) written as fp64 partials by the epilogue of the 3x3

@@ -7,7 +7,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda *a: os.path.join(ROOT, *a)
-DOM = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 2, 0, false>"
+DOM = "conv3x3_halo_m16_kernel<128, false, 0, 0, false>"
 WG = "wgrad_halo9_bf3_kernel<32, 64, 64, 2>"
 BEGIN, END = "<!-- numbers:begin -->", "<!-- numbers:end -->"
 
