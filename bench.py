@@ -487,16 +487,16 @@ def main():
 
     traffic, traffic_dom, traffic_note = None, None, "no PMC profile for this build"
     try:                                             # HBM bytes per launch of the dominant class, from the committed PMC pass of THIS build
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
         if pm.get("source_hash") != source_hash():
-            traffic_note = f"profiles/r03_pmc_traffic.json was taken on sources {pm.get('source_hash')} != this build {source_hash()}: refused"
+            traffic_note = f"profiles/r04_pmc_traffic.json was taken on sources {pm.get('source_hash')} != this build {source_hash()}: refused"
         elif pm.get("batch_per_gpu") != B or pm.get("full_step") != (not args.phase_b_only):
-            traffic_note = "profiles/r03_pmc_traffic.json was taken on another workload: refused"
+            traffic_note = "profiles/r04_pmc_traffic.json was taken on another workload: refused"
         else:
             traffic = pm["conv_igemm"]["hbm_bytes_per_launch"]
             kt = pm.get("per_kernel_bytes_per_launch", {}).get(DOMINANT_KERNEL)
             traffic_dom = kt["fetch"] + kt["write"] if kt else None
-            traffic_note = "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE in separate passes, profiles/r03_pmc_traffic.json (same sources)"
+            traffic_note = "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE in separate passes, profiles/r04_pmc_traffic.json (same sources)"
     except (OSError, KeyError, ValueError):
         pass
 

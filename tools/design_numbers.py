@@ -1,5 +1,5 @@
 """Rewrites the 'Numbers of the final build' paragraph of DESIGN.md (and the cross-check line of profiles/README.md) from the
-committed profiles/r03_* files, so that the documents quote exactly what the files hold."""
+committed profiles/r04_* files, so that the documents quote exactly what the files hold."""
 import csv
 import json
 import os
@@ -8,20 +8,24 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda *a: os.path.join(ROOT, *a)
 DOM = "conv3x3_halo_m16_kernel<128, false, 0, 0, false>"
-WG = "wgrad_halo9_bf3_kernel<32, 64, 64, 2>"
+WG = "wgrad_halo9_spec_kernel<32>"
+sys_path = os.path.join(ROOT, "tools")
+import sys
+sys.path.insert(0, sys_path)
+from kname import pretty
 BEGIN, END = "<!-- numbers:begin -->", "<!-- numbers:end -->"
 
 
 def main():
-    d = json.loads(open(P("profiles", "r03_bench_b2048.json")).read().strip().splitlines()[-1])
-    u = json.loads(open(P("profiles", "r03_bench_b2048_under_rocprof_single_stream.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(P("profiles", "r04_bench_b2048.json")).read().strip().splitlines()[-1])
+    u = json.loads(open(P("profiles", "r04_bench_b2048_under_rocprof_single_stream.json")).read().strip().splitlines()[-1])
     tr, total = None, 0.0
-    for row in csv.DictReader(open(P("profiles", "r03_kernel_stats_b2048_single_stream.csv"))):
+    for row in csv.DictReader(open(P("profiles", "r04_kernel_stats_b2048_single_stream.csv"))):
         total += float(row["TotalDurationNs"])
-        if DOM in row["Name"]:
+        if pretty(row["Name"]) == DOM:
             tr = (int(row["Calls"]), float(row["AverageNs"]) / 1e3)
-    t = json.load(open(P("profiles", "r03_pmc_traffic.json")))
-    m = json.load(open(P("profiles", "r03_pmc_mfma_busy.json")))["kernels"]
+    t = json.load(open(P("profiles", "r04_pmc_traffic.json")))
+    m = json.load(open(P("profiles", "r04_pmc_mfma_busy.json")))["kernels"]
     k0, k1 = m[DOM], m[WG]
     r = d["roofline"]
     lc, wg, nf, bf = r["launch_class"], d["kernels"]["conv_wgrad"], r["native_fp32"], r["split_bf16"]
@@ -29,9 +33,9 @@ def main():
     kb = kt["fetch"] + kt["write"]
     cb = d["cpu_baseline"]
     nums = f'''{BEGIN}
-Numbers of the final build (1× MI355X, `profiles/r03_bench_b2048.json`): **{d['value'] / 1e3:.2f} k patch-images/s for the full minibatch step at
+Numbers of the final build (1× MI355X, `profiles/r04_bench_b2048.json`): **{d['value'] / 1e3:.2f} k patch-images/s for the full minibatch step at
 B = 2048** ({d['ms_per_step']:.1f} ms incl. the CER update; {d['overlap']['ms_per_step_single_stream']:.1f} ms single-stream; {d['full_step_without_cer_update']['ms_per_step']:.1f} ms = {d['full_step_without_cer_update']['value'] / 1e3:.2f} k without the CER update, the round-2
-timed region, where round 2 measured 150.6 ms = 13.60 k), of which Phase B alone is {d['phase_b']['ms_per_step']:.1f} ms = {d['phase_b']['value'] / 1e3:.2f} k img/s ({d['phase_b']['end_to_end_tflops']:.1f} TFLOP/s end to end on the
+timed region; round 3: 104.3 ms, round 2: 150.6 ms), of which Phase B alone is {d['phase_b']['ms_per_step']:.1f} ms = {d['phase_b']['value'] / 1e3:.2f} k img/s ({d['phase_b']['end_to_end_tflops']:.1f} TFLOP/s end to end on the
 reference-faithful 9.846 GFLOP/img); configs[1] (B = 512, Phase B) {d['configs1_b512']['value'] / 1e3:.2f} k img/s ({d['configs1_b512']['ms_per_step']:.1f} ms); `--select_before_clean` {d['full_step_select_before_clean']['value'] / 1e3:.2f} k.
 The same steps on the same box in the other two arithmetic forms: three-way bf16 split (round 2's) {bf['value'] / 1e3:.2f} k img/s
 ({bf['ms_per_step_single_stream']:.1f} ms single-stream; its dominant kernel {bf['achieved']:.1f} TFLOP/s = {bf['frac']:.3f} of 419.4), native fp32 MFMA {nf['value'] / 1e3:.2f} k (conv class {nf['conv_igemm_tflops']:.1f} TFLOP/s =
@@ -39,13 +43,13 @@ The same steps on the same box in the other two arithmetic forms: three-way bf16
 `roofline` = the dominant kernel `{DOM}` ({100 * r['share_of_step']:.1f} % of the step, {r['launches_per_step']:.0f} launches/step): **{r['achieved']:.1f} TFLOP/s
 fp32-equivalent, `frac` {r['frac']:.3f}** of 838.9 (fp16 dense ÷ 3; {r['frac_of_the_six_mfma_peak']:.3f} of the 419.4 the six-MFMA form was priced against); average launch {r['avg_launch_us']:.1f} µs
 from bench.py's HIP events — the rocprofv3 trace of a run made of identical full steps gives {tr[1]:.1f} µs for the same kernel
-(`r03_kernel_stats_b2048_single_stream.csv`, {tr[0]} calls; the JSON line of that very run: {u['roofline']['avg_launch_us']:.1f}); HBM traffic {kb / 1e9:.2f} GB per launch against
+(`r04_kernel_stats_b2048_single_stream.csv`, {tr[0]} calls; the JSON line of that very run: {u['roofline']['avg_launch_us']:.1f}); HBM traffic {kb / 1e9:.2f} GB per launch against
 {r['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic ({kb / r['algorithmic_bytes_per_launch']:.2f}×). `roofline.launch_class` = all {lc['launches_per_step']:.0f} `qea_conv_igemm` launches of a step: {lc['achieved']:.1f} TFLOP/s, {lc['frac']:.3f} of the
 {lc['peak']:.1f} blend ({100 * lc['split_f16_flop_fraction']:.1f} % of the flops in the fp16 split), {t['conv_igemm']['hbm_bytes_per_launch'] / 1e9:.2f} GB of HBM traffic per launch against {lc['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic
-({t['conv_igemm']['hbm_bytes_per_launch'] / lc['algorithmic_bytes_per_launch']:.2f}×). `kernels.conv_wgrad`: {wg['tflops']:.1f} TFLOP/s over {wg['launches_per_step']:.0f} launches ({wg['ms_per_step']:.1f} ms; round 2: 188.6 TFLOP/s, 36.5 ms), `frac` {wg['frac']:.3f} of its
+({t['conv_igemm']['hbm_bytes_per_launch'] / lc['algorithmic_bytes_per_launch']:.2f}×). `kernels.conv_wgrad`: {wg['tflops']:.1f} TFLOP/s over {wg['launches_per_step']:.0f} launches ({wg['ms_per_step']:.1f} ms; round 3: 273.6 TFLOP/s, 25.2 ms; round 2: 188.6, 36.5), `frac` {wg['frac']:.3f} of its
 {wg['peak']:.1f} blend, HBM {t['conv_wgrad']['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch against {wg['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic ({t['conv_wgrad']['hbm_bytes_per_launch'] / wg['algorithmic_bytes_per_launch']:.2f}×). BiLSTM steps {d['kernels']['lstm_step']['ms_per_step']:.1f} ms ({d['kernels']['lstm_step']['launches_per_step']:.0f} launches).
-`cpu_baseline`: {cb['value']:.1f} img/s at B = {cb['batch']} (B = 128: {cb['b128']['value']:.1f}; {cb['cores']} threads). PMC (`r03_pmc_mfma_busy.json`, under the profiler): dominant
-kernel {k0['mfma_busy']} MFMA-busy at a held {k0['clock_ghz']} GHz (the bf16 form: 0.72 at 1.89), nine-tap wgrad {k1['mfma_busy']} at {k1['clock_ghz']} GHz; sum of kernel time in the
+`cpu_baseline`: {cb['value']:.1f} img/s at B = {cb['batch']} (B = 128: {cb['b128']['value']:.1f}; {cb['cores']} threads). PMC (`r04_pmc_mfma_busy.json`, under the profiler): dominant
+kernel {k0['mfma_busy']} MFMA-busy at a held {k0['clock_ghz']} GHz = {k0['mfma_busy'] * k0['clock_ghz'] / 2.4:.3f} of the peak (round 3: 0.647 at 1.81 = 0.488), no LDS bank conflicts (round 3's swizzle family: 0.135 per wave cycle); nine-tap wgrad (producer / consumer form) {k1['mfma_busy']} at {k1['clock_ghz']} GHz (round 3: 0.412 at 2.2); sum of kernel time in the
 single-stream trace {total / 13e6:.1f} ms per step.
 {END}'''
     s = open(P("DESIGN.md")).read()

@@ -9,6 +9,9 @@ is summed over the 8 XCDs); clock_ghz = shader cycles / kernel duration.  Time-w
 """
 import collections, csv, glob, json, os, sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import pretty
+
 CUS = 256
 
 
@@ -17,8 +20,7 @@ def main():
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     seen = set()
     for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-        n = n.split("(")[0]
+        n = pretty(r["Kernel_Name"])
         per[n][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (r["Dispatch_Id"],)
         if key not in seen:

@@ -12,6 +12,9 @@ kernels are charged to the wgrad launch they belong to.
 """
 import collections, csv, glob, json, os, sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import pretty
+
 CLASSES = {
     "conv_igemm": (("conv_igemm_kernel", "conv_igemm_bf3_kernel", "conv_igemm_bf3w_kernel", "conv_igemm_p3_kernel", "conv3x3_halo_kernel",
                     "conv3x3_halo_bf3_kernel", "conv3x3_halo_m16_kernel", "gemm1x1_f16_kernel"), ()),
@@ -53,7 +56,7 @@ def main():
         f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                n = pretty(r["Kernel_Name"])
                 per_kernel[n][col] += float(r["Counter_Value"]) * 1024 * mul
                 per_kernel[n][2] += col == 0
     out["per_kernel_bytes_per_launch"] = {n: {"launches": v[2], "fetch": round(v[0] / max(1, v[2])), "write": round(v[1] / max(1, v[2]))}
