@@ -150,6 +150,26 @@ def cpu_baseline():
             "b128": b128, "b32": b32, "host": host}
 
 
+def small_batch_legs():
+    """The reference's own batch regime (area_cli.py:11 --batch_size 32; one document of ~20 strips in the patch flow): the Phase-B step
+    at B = 32 and B = 8, eager and as ONE hipGraph replay (area_cli's [new] --graph), each in a child process of this bench
+    (VERDICT r3 #4: the numbers a maintainer who runs the README command gets)."""
+    import subprocess
+    res = {"note": "Phase-B step (UNet train-BN -> CRNN -> CTC + MSE -> backward -> Adam) at the reference's batch sizes; ms per step; "
+                   "'graph' = one hipGraph replay per step (area_cli --graph), 'eager' = ~600 launches from Python"}
+    for b in (32, 8):
+        for mode, flag in (("graph", ["--graph"]), ("eager", [])):
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(b), "--phase-b-only", "--steps", "40", "--warmup", "3",
+                                    "--no-cpu-baseline", "--no-secondary"] + flag, capture_output=True, text=True, timeout=180)
+                d = json.loads(p.stdout.strip().splitlines()[-1])
+                res[f"b{b}_{mode}_ms"] = round(d["ms_per_step"], 3)
+            except Exception as e:                          # a failed leg must not cost the headline line
+                res[f"b{b}_{mode}_ms"] = None
+                res.setdefault("errors", []).append(f"B={b} {mode}: {type(e).__name__}")
+    return res
+
+
 DOMINANT_KERNEL = "conv3x3_halo_m16_kernel<128, false, 0, 0, false>"   # (round 4: the 16x16x32 form of the two-way fp16 LDS-halo conv, 64-channel chunks)
 DOMINANT_KERNEL_BF16 = "conv3x3_halo_bf3_kernel<64, 128, 4, false, 0, 3>"
 
@@ -609,6 +629,8 @@ def main():
             out["full_step_select_before_clean"] = sel_first
         if c1 is not None:
             out["configs1_b512"] = c1
+        if world == 1 and not args.no_secondary and not args.phase_b_only and not args.graph and B >= 512:
+            out["small_batch"] = small_batch_legs()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

@@ -75,13 +75,16 @@ class CRNN(nn.Module):
             raise QeaError("CRNN: batchnorm1/batchnorm2 must be in the same mode")
         return modes.pop()
 
-    def forward(self, x, replica_groups=1, backward_group=None):
+    def forward(self, x, replica_groups=1, backward_group=None, group_sizes=None):
         """x [B,1,32,W] -> log-probs [T,B,vocab].  replica_groups = R (new, additive): x holds R jitter replicas
         of the same strips stacked replica-major; batch-stat BatchNorm runs per replica group, so one call equals R
         sequential calls of the reference on the R replicas (see CRNNEngine.forward).
         backward_group = g (new, additive): only replica group g will be back-propagated (the area flow keeps the last
         replica's loss only, train_nn_area.py:269-271).  The other groups' log-probs are returned DETACHED, so no gradient
-        can reach them, and the backward pass runs on that group's B/R samples instead of on all B."""
+        can reach them, and the backward pass runs on that group's B/R samples instead of on all B.
+        group_sizes = [n_0, n_1, ...] (new, additive; round 4): RAGGED BatchNorm groups — the batch is the concatenation of groups of n_i
+        samples (e.g. the jittered strips of several documents, document-major, replica-minor); batch-stat BatchNorm runs per group and
+        the running statistics are updated once per group in order = the reference's sequential calls (train_nn_patch.py:288-303)."""
         _require_cuda(x, "CRNN")
         eng = self._engine()
         ensure_flat(self)
@@ -92,6 +95,11 @@ class CRNN(nn.Module):
         wants = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         skip = self.__dict__.get("_qea_skip_param_grads", False)
         R = int(replica_groups)
+        if group_sizes is not None:
+            if R != 1 or backward_group is not None:
+                raise ValueError("group_sizes excludes replica_groups / backward_group")
+            return CRNNFn.apply(x, anchor if wants else None, eng, self._bn_mode(), bool(self.__dict__.get("_qea_nan_scrub", False)), not skip,
+                                tuple(int(v) for v in group_sizes), -1)
         g = -1 if backward_group is None or R <= 1 else int(backward_group)
         if g >= R:
             raise ValueError(f"backward_group {g} out of range for {R} replica groups")

@@ -46,9 +46,19 @@ class CRNNEngine:
         if H != 32 or W % 4:
             raise ValueError(f"CRNN input must be [B,1,32,W] with W % 4 == 0, got {H}x{W}")
         c = self.cp
-        if B % groups:
-            raise ValueError(f"batch {B} is not a multiple of groups={groups}")
-        ctx = {"x": x, "B": B, "H": H, "W": W, "bn_training": bn_training, "groups": groups} if need_grad else None
+        # groups: an int (equal groups) or a sequence of per-group SAMPLE counts (ragged groups, round 4: the strips of several
+        # documents in one pass, each document its own BatchNorm batch as in the reference's one-document-per-call loop)
+        if isinstance(groups, int):
+            if B % groups:
+                raise ValueError(f"batch {B} is not a multiple of groups={groups}")
+            sizes = [B // groups] * groups
+        else:
+            sizes = [int(v) for v in groups]
+            if sum(sizes) != B or any(v <= 0 for v in sizes):
+                raise ValueError(f"group sizes {sizes} do not partition the batch of {B}")
+            groups = len(sizes)
+        starts = [sum(sizes[:i]) for i in range(groups)]
+        ctx = {"x": x, "B": B, "H": H, "W": W, "bn_training": bn_training, "groups": groups, "group_sizes": sizes} if need_grad else None
 
         # producer-carried abs-max of every tensor a split-fp16 conv / wgrad launch consumes (amx[name]; None when that split is off)
         pool_ = ops.amax_pool(dev)
@@ -98,12 +108,14 @@ class CRNNEngine:
                            ldx=cin, ldy=512, bias=P[c + name + ".bias"], w_src=("fwd", P[c + name + ".weight"]), x_amax=amx[cur_name])
             amx["a" + name[-1]] = slot()
             G = groups if bn_training else 1
-            Mg = M // G
+            gb = [(starts[gi], sizes[gi]) for gi in range(G)] if bn_training else [(0, B)]     # (first sample, samples) of every group
             coef = torch.empty(G, 4, 512, device=dev)
             stat64 = torch.empty(G, 2, 512, device=dev, dtype=torch.float64) if (bn_training and need_grad) else None
             a = torch.empty(M, 512, device=dev)
             for gi in range(G):
-                yg, ag = y[gi * Mg:(gi + 1) * Mg], a[gi * Mg:(gi + 1) * Mg]
+                b0, bg = gb[gi]
+                Mg = bg * h * w
+                yg, ag = y[b0 * h * w:(b0 + bg) * h * w], a[b0 * h * w:(b0 + bg) * h * w]
                 if bn_training:
                     ops.bn_train_stats(yg, 512, Mg, 512, P[c + bn + ".weight"], P[c + bn + ".bias"], BN_EPS, BN_MOMENTUM,
                                        Bf[c + bn + ".running_mean"], Bf[c + bn + ".running_var"], coef[gi, 0], coef[gi, 1], coef[gi, 2],
@@ -116,8 +128,7 @@ class CRNNEngine:
                     if gi == 0:
                         p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
                         amx["p6"] = slot()
-                    bg = B // G
-                    ops.bn_apply_pool(yg, 512, ag, 512, p6[gi * bg * (h // 2) * w:(gi + 1) * bg * (h // 2) * w], 512, bg, h, w, 512, coef[gi, 2],
+                    ops.bn_apply_pool(yg, 512, ag, 512, p6[b0 * (h // 2) * w:(b0 + bg) * (h // 2) * w], 512, bg, h, w, 512, coef[gi, 2],
                                       coef[gi, 3], 2, 1, relu=True, amax=amx["a" + name[-1]], pooled_amax=amx["p6"])
                 else:
                     ops.bn_apply(yg, 512, ag, 512, Mg, 512, coef[gi, 2], coef[gi, 3], relu=True, amax=amx["a" + name[-1]])
@@ -125,7 +136,7 @@ class CRNNEngine:
             dims[name] = (h, w)
             cur, cur_name = a, "a" + name[-1]
         if bn_training:
-            fs.ibuf.add_(groups)
+            fs.ibuf.add_(groups)                                   # num_batches_tracked: one per group, as sequential calls
         amx["seq"] = slot()
         if not FUSE_POOL:
             p6 = torch.empty(B * (h // 2) * w, 512, device=dev)
@@ -312,14 +323,18 @@ class CRNNEngine:
             dy_ = torch.empty(M, 512, device=dev)
             dy_amax = slot()
             NG = coef.shape[0]
-            Mg = M // NG
+            gsz = ctx.get("group_sizes") if NG > 1 else None
+            if gsz is None or len(gsz) != NG:
+                gsz = [B // NG] * NG
             for gi in range(NG):
-                sl = slice(gi * Mg, (gi + 1) * Mg)
+                b0 = sum(gsz[:gi])
+                Mg = gsz[gi] * h * w
+                sl = slice(b0 * h * w, b0 * h * w + Mg)
                 st = acts["st" + k]
                 if da is None:
                     # conv6's output went through the (2,1) pool only: its backward rides in the two passes of BatchNorm2's (qea_bn_bwd_pool)
-                    Bg = B // NG
-                    psl = slice(gi * Bg * (h // 2) * w, (gi + 1) * Bg * (h // 2) * w)
+                    Bg = gsz[gi]
+                    psl = slice(b0 * (h // 2) * w, (b0 + Bg) * (h // 2) * w)
                     ops.bn_bwd_pool(None, 0, dp6[psl], 512, 1, acts["y" + k][sl], 512, Bg, h, w, 512, P[c + bn + ".weight"], coef[gi, 0],
                                     coef[gi, 1], bn_training, G[c + bn + ".weight"] if param_grads else None,
                                     G[c + bn + ".bias"] if param_grads else None, dy_[sl], 512, accumulate=True,
@@ -395,7 +410,7 @@ class CRNNEngine:
         T = ctx["T"]
         dims = ctx["dims"]
         sub = dict(ctx)
-        sub.update(B=k, groups=1, grad_group=-1, _g=g, x=ctx["x"][b0:b0 + k])
+        sub.update(B=k, groups=1, group_sizes=[k], grad_group=-1, _g=g, x=ctx["x"][b0:b0 + k])
         acts = {}
         for name, t in ctx["acts"].items():
             if t is None:

@@ -199,6 +199,29 @@ class TrainerCore:
             losses.append(self.primary_loss_fn(scores, y, pred_size, y_size))
         return losses, R * k
 
+    def _replica_losses_docs(self, crops_list, noiser, R):
+        """[new] Phase A of SEVERAL documents in one CRNN pass (--docs_per_step): the R jittered copies of every document's strips,
+        document-major and replica-minor, with one BatchNorm group per (document, replica) — ragged groups, CRNN.forward(group_sizes=...)
+        — so that values, gradients and running statistics are those of the reference's sequential loop (train_nn_patch.py:288-303 per
+        document, one document after the other).  Returns ([per-document list of R losses], black-box calls).  HIP path only."""
+        noisy = torch.cat([noiser.batch(c, replicas=R)[0] for c in crops_list])
+        ocr_labels = self.ocr.get_labels(noisy.cpu())
+        sizes = [c.shape[0] for c in crops_list for _ in range(R)]
+        scores = self.crnn_model(noisy, group_sizes=sizes)
+        out, a = [], 0
+        for c in crops_list:
+            k = c.shape[0]
+            out_size = torch.tensor([scores.shape[0]] * k, dtype=torch.int)
+            losses = []
+            for _ in range(R):
+                labels = ocr_labels[a:a + k]
+                y = torch.tensor([self.char_to_index[ch] for ch in "".join(labels)], dtype=torch.int)
+                y_size = torch.tensor([len(l) for l in labels], dtype=torch.int)
+                losses.append(self.primary_loss_fn(scores[:, a:a + k, :], y, out_size, y_size))
+                a += k
+            out.append(losses)
+        return out, noisy.shape[0]
+
     def _num_bb_samples(self, n):
         return max(1, math.ceil(n * (1 - self.train_batch_prop)))
 

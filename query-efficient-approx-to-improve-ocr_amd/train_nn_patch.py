@@ -92,6 +92,11 @@ class TrainNNPrep(TrainerCore):
                 X_all = (images if torch.is_tensor(images) else torch.stack(list(images))).to(self.device)
                 with torch.no_grad():                            # eval-mode BatchNorm: a document's output does not depend on its batch
                     preds_all = self.prep_model(X_all) if n_docs > 1 else None
+                # [new] the CRNN side of Phase A for the N documents in one pass (ragged BatchNorm groups) where nothing per document has to
+                # happen in between: HIP path, more than one replica, no label-history pass (--inner_limit_skip runs per document)
+                batched_a = (n_docs > 1 and self.backend.gpu_jitter and self.inner_limit > 1 and not self.inner_limit_skip
+                             and self.device.type == "cuda" and getattr(self, "_batch_phase_a", True))
+                pending = []
                 for i in range(n_docs):
                     with torch.no_grad():
                         pred = preds_all[i] if preds_all is not None else self.prep_model(X_all[i:i + 1])[0]
@@ -123,6 +128,9 @@ class TrainNNPrep(TrainerCore):
                         loss.backward()
                         total_bb_calls += crops.shape[0]
                         epoch_bb_calls += crops.shape[0]
+                    if batched_a:                                # [new] all documents' replicas go through the CRNN together below
+                        pending.append(crops)
+                        continue
                     rep_losses, calls = self._replica_losses(crops, noiser, self.inner_limit - n_skip)
                     total_bb_calls += calls
                     epoch_bb_calls += calls
@@ -134,6 +142,18 @@ class TrainNNPrep(TrainerCore):
                         approx_loss += total.item()
                         total.backward()
                     CRNN_training_loss += approx_loss / max(1, self.inner_limit)
+                if pending:
+                    # [new] --docs_per_step N: ONE jitter + black-box + CRNN pass for the N documents, one BatchNorm group per
+                    # (document, replica) in the order of the sequential loop; the sum of all losses is back-propagated once
+                    doc_losses, calls = self._replica_losses_docs(pending, noiser, self.inner_limit)
+                    total_bb_calls += calls
+                    epoch_bb_calls += calls
+                    total = None
+                    for losses in doc_losses:
+                        for l in losses:
+                            total = l if total is None else total + l
+                    total.backward()
+                    CRNN_training_loss += sum(float(l.item()) for losses in doc_losses for l in losses) / max(1, self.inner_limit)
                 if self.inner_limit:
                     self._step_crnn()
                 # ---------------- Phase B ----------------

@@ -370,6 +370,61 @@ def test_replica_groups_equal_sequential_passes(mode):
             assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), n
 
 
+@pytest.mark.parametrize("mode", ["split_f16", "split_bf16"])
+def test_ragged_bn_groups_equal_sequential_passes(mode):
+    """CRNN.forward(group_sizes=[...]) (round 4: the jittered strips of SEVERAL documents in one pass, one BatchNorm group per (document,
+    replica), groups of different sizes) == one CRNN pass per group in that order (train_nn_patch.py:288-303 document after document):
+    same log-probs, gradients of the summed losses, running statistics.  Tolerances as in the equal-groups test."""
+    from models.model_crnn import CRNN
+    from oracle import model_oracle as mo
+    from qea import ops
+    from qea.loss import CTCLoss
+    prev_mode = ops.set_mfma_mode(mode)
+    sizes = [3, 3, 5, 5, 2]                                            # e.g. two replicas of a 3-strip and of a 5-strip document, then 2 strips
+    sc = mo.seeded_state(mo.crnn_state_shapes(), 9)
+    xs = [H.synth_images(n, 70 + i).cuda() for i, n in enumerate(sizes)]
+    labels = [H.synth_labels(n, 80 + i, 1, 8) for i, n in enumerate(sizes)]
+
+    def make():
+        net = CRNN(95, False)
+        net.load_state_dict(sc)
+        net = net.cuda().train()
+        net.register_backward_hook(net.backward_hook)
+        net.zero_grad()
+        return net
+    seq = make()
+    lps = []
+    for x, lab in zip(xs, labels):
+        lp = seq(x)
+        y, ysz = H.encode(lab)
+        CTCLoss()(lp, y, torch.full((x.shape[0],), 31, dtype=torch.int), ysz).backward()
+        lps.append(lp.detach())
+    fused = make()
+    lp_all = fused(torch.cat(xs), group_sizes=sizes)
+    total, a = 0, 0
+    for n, lab in zip(sizes, labels):
+        y, ysz = H.encode(lab)
+        total = total + CTCLoss()(lp_all[:, a:a + n, :], y, torch.full((n,), 31, dtype=torch.int), ysz)
+        a += n
+    total.backward()
+    ops.set_mfma_mode(prev_mode)
+    if mode == "split_bf16":
+        assert torch.equal(lp_all.detach(), torch.cat(lps, dim=1))
+    else:
+        assert (lp_all.detach() - torch.cat(lps, dim=1)).abs().max().item() < 5e-6
+    for (n, a_), (_, b) in zip(fused.named_parameters(), seq.named_parameters()):
+        if mode != "split_bf16" and n in ("convo.conv5.bias", "convo.conv6.bias"):
+            continue
+        assert _rel(a_.grad, b.grad) < 2e-5, n
+    for (n, a_), (_, b) in zip(fused.named_buffers(), seq.named_buffers()):
+        if mode == "split_bf16" or not a_.is_floating_point():
+            assert torch.equal(a_, b), n
+        else:
+            assert (a_ - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), n
+    with pytest.raises(ValueError):
+        fused(torch.cat(xs), group_sizes=[3, 3])
+
+
 @pytest.mark.parametrize("g", [2, 0])
 def test_backward_group_equals_sequential_last_replica(g):
     """train_nn_area.py:269-271 back-propagates the LAST replica only.  CRNN.forward(backward_group=g) returns the same

@@ -93,6 +93,45 @@ def test_patch_trainer_hip_docs_per_step(tmp_path):
     assert set(t.sampler.all_cers.keys()) == set(names) and all(len(v) == 1 for v in t.sampler.all_cers.values())
 
 
+def test_patch_trainer_docs_per_step_batches_phase_a(tmp_path):
+    """[new] --docs_per_step N on the HIP path: the CRNN side of Phase A runs ONCE for the N documents (ragged BatchNorm groups, one per
+    (document, replica)) instead of once per document; with the jitter pinned to a function of the image content, the CRNN gradient that
+    the first Adam(CRNN) step consumes equals the one of the per-document loop (the same trainer with the batching switched off)."""
+    from datasets.synthetic import SyntheticPatches
+    from train_nn_patch import TrainNNPrep
+    import transform_helper
+    res = {}
+    real_batch = transform_helper.AddGaussianNoice.batch
+
+    def pinned(self, imgs, replicas=1, **_k):
+        out = torch.cat([torch.clamp(imgs - 0.05 * (r + 1) * torch.sin(37.0 * imgs + r), 0, 1) for r in range(replicas)])
+        return out, None
+    transform_helper.AddGaussianNoice.batch = pinned
+    try:
+        for batched in (True, False):
+            torch.manual_seed(0)
+            tr = SyntheticPatches(4, seed=1)
+            args = _args("p", tmp_path / f"exp{int(batched)}", inner_limit=2, docs_per_step=2)
+            t = TrainNNPrep(args, train_set=tr, val_set=SyntheticPatches(1, seed=2, include_name=False))
+            t._batch_phase_a = batched
+            calls, grads = [], []
+            orig = t._replica_losses_docs
+            t._replica_losses_docs = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            orig_step = t._step_crnn
+
+            def spy(orig_step=orig_step, t=t, grads=grads):
+                grads.append(torch.cat([p.grad.detach().flatten().clone() for p in t.crnn_model.parameters()]))
+                return orig_step()
+            t._step_crnn = spy
+            t.train()
+            assert (len(calls) > 0) == batched and len(grads) == 2
+            res[batched] = grads[0]
+    finally:
+        transform_helper.AddGaussianNoice.batch = real_batch
+    d = (res[True].double() - res[False].double()).norm().item() / res[False].double().norm().item()
+    assert d <= 1e-4, d
+
+
 def test_area_trainer_graph_replays_phase_b(tmp_path):
     """[new] --graph: Phase B of the area trainer as one hipGraph per shape (two eager steps, then capture, then replays) is the
     same training as the eager loop: same losses step by step, same weights after six steps."""
