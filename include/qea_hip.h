@@ -229,8 +229,14 @@ typedef struct qea_wgrad_desc {
    * fp16 split: three MFMAs per product instead of six (see qea_conv_desc.x_absmax).  Other launches ignore them. */
   const float* p_absmax;
   const float* q_absmax;
+  /* ABI v8 (the descriptor grew at its end: v7 callers must re-compile).  dbias [R] (NULL = off): the bias gradient = column sums of p
+   * (`nn.Conv2d(bias=True)` under autograd, models/model_crnn.py:38-45), accumulated with the same `accumulate` flag as dw.  Taken only by the
+   * producer / consumer nine-tap form, where every p element passes through the staging waves' registers anyway (no pass of its own,
+   * no qea_colsum launch): ask qea_conv_wgrad_fuses_bias(d) first — with dbias set, any other form refuses the call. */
+  float* dbias;
 } qea_wgrad_desc;
 
+int qea_conv_wgrad_fuses_bias(const qea_wgrad_desc* d);
 size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d);
 int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream);
 

@@ -1047,13 +1047,25 @@ __device__ __forceinline__ f16x8 tr_pair128(const char* base) {   // this lane's
   return __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// out[c] (+)= sum over the nblk partial rows of ws[k][c]: one wave per channel, lanes stride the rows, fixed order
+__global__ void bias_finalize_kernel(const double* __restrict__ ws, int nblk, int R, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= R) return;
+  const int lane = threadIdx.x & 63;
+  double a = 0;
+  for (int k = lane; k < nblk; k += 64) a += ws[(size_t)k * R + c];
+  a = qea_wave_sum_d(a);
+  if (lane == 0) out[c] = accumulate ? out[c] + (float)a : (float)a;
+}
+
 template <int SW>
 constexpr size_t halo9_spec_lds() { return (size_t)2 * (2 * 64 * 64 * 2 + 2 * ((64 / SW + 2) * (SW + 2)) * 64 * 2); }
 
 template <int SW>
 __global__ __launch_bounds__(512) void wgrad_halo9_spec_kernel(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ ws, int B,
                                                                int H, int W, int R, int C, int ldp, int ldq, Halo9Plan hp,
-                                                               const float* __restrict__ pmax, const float* __restrict__ qmax) {
+                                                               const float* __restrict__ pmax, const float* __restrict__ qmax,
+                                                               double* __restrict__ bias_ws) {
   constexpr int TH = 64 / SW, HWD = SW + 2, HH = TH + 2, HP = HH * HWD;
   constexpr int P_PLANE_B = 64 * 64 * 2, Q_PLANE_B = HP * 64 * 2;            // bytes per plane
   constexpr int BUF_B = 2 * P_PLANE_B + 2 * Q_PLANE_B;                        // one buffer: P h, P l, Q h, Q l
@@ -1076,6 +1088,10 @@ __global__ __launch_bounds__(512) void wgrad_halo9_spec_kernel(const float* __re
     const int pt = tid - 256;
     constexpr int NP = 64 * 16 / 256, NQ = (HP * 16 + 255) / 256;
     f32x4 preg[NP], qreg[NQ];
+    // bias gradient (round 4): the column sums of dY ride with the staging — every dY element passes through these registers exactly once
+    // per channel-block column, so the workgroups of column block 0 add what they stage (fp64, channels pt % 16 * 4 ... + 3 of this thread)
+    const bool do_bias = bias_ws != nullptr && c_blk == 0;
+    double bsum[4] = {0.0, 0.0, 0.0, 0.0};
     auto fetch = [&](int tile) {
       const int tx = tile % hp.tiles_x;
       const int ty = (tile / hp.tiles_x) % hp.tiles_y;
@@ -1109,6 +1125,10 @@ __global__ __launch_bounds__(512) void wgrad_halo9_spec_kernel(const float* __re
       for (int i = 0; i < NP; ++i) {
         const int e = pt + 256 * i;
         const int o = row_off(e / 16, e % 16);
+        if (do_bias) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) bsum[k] += (double)preg[i][k];
+        }
         f16x4 h, l;
         qea_split2_f16(preg[i], sp, h, l);
         *reinterpret_cast<f16x4*>(Ps + o) = h;
@@ -1137,6 +1157,23 @@ __global__ __launch_bounds__(512) void wgrad_halo9_spec_kernel(const float* __re
       if (t + 1 < ntl) stage(lds + ((t + 1) & 1) * BUF_B);
       if (t + 2 < ntl) fetch(split + (t + 2) * hp.splits);
       __syncthreads();                                       // consumers done with buffer t & 1, buffer (t + 1) & 1 complete
+    }
+    if (do_bias) {
+      // lanes l, l + 16, l + 32, l + 48 of a wave hold the same four channels (pixel rows 4 apart): wave sums, then one partial row per
+      // (split, producer wave): [splits * 4][R] doubles, summed in a fixed order by bias_finalize_kernel (fp64 to the end, as qea_colsum:
+      // in front of a batch-statistics BatchNorm this gradient is an exact zero made of cancelling terms)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double v = bsum[k];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        bsum[k] = v;
+      }
+      if (lane < 16) {
+        double* dst = bias_ws + (size_t)(split * 4 + (wave - 4)) * R + r0 + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = bsum[k];
+      }
     }
     return;
   }
@@ -1271,7 +1308,7 @@ int launch_halo9_any(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s)
 }
 
 template <int SW>
-int launch_halo9_spec(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
+int launch_halo9_spec(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s, double* bias_ws) {
   constexpr size_t lds = halo9_spec_lds<SW>();
   const long long grid = (long long)h.r_blks * h.c_blks * h.splits;
   auto kern = wgrad_halo9_spec_kernel<SW>;
@@ -1281,17 +1318,24 @@ int launch_halo9_spec(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s
     return QEA_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C, d->ldp, d->ldq, h,
-                     d->p_absmax, d->q_absmax);
+                     d->p_absmax, d->q_absmax, bias_ws);
   return QEA_OK;
 }
 
-int launch_halo9(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s) {
-  if (h.spec) return h.sw == 32 ? launch_halo9_spec<32>(d, h, s) : launch_halo9_spec<16>(d, h, s);
+int launch_halo9(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s, double* bias_ws = nullptr) {
+  if (h.spec) return h.sw == 32 ? launch_halo9_spec<32>(d, h, s, bias_ws) : launch_halo9_spec<16>(d, h, s, bias_ws);
   if (h.sw == 32) return h.rb == 64 ? launch_halo9_any<32, 64, 64>(d, h, s) : launch_halo9_any<32, 32, 32>(d, h, s);
   return h.rb == 64 ? launch_halo9_any<16, 64, 64>(d, h, s) : launch_halo9_any<16, 32, 32>(d, h, s);
 }
 
 }  // namespace
+
+extern "C" int qea_conv_wgrad_fuses_bias(const qea_wgrad_desc* d) {
+  if (!d || d->R <= 0 || d->C <= 0 || d->B <= 0) return 0;
+  if (!((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23)) return 0;
+  const Halo9Plan h9 = halo9_plan(d);
+  return (h9.ok && h9.spec) ? 1 : 0;
+}
 
 extern "C" size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d) {
   if (!d || d->R <= 0 || d->C <= 0 || d->B <= 0) return 0;
@@ -1301,7 +1345,7 @@ extern "C" size_t qea_conv_wgrad_workspace_bytes(const qea_wgrad_desc* d) {
   }
   if ((d->tile == 0 && qea_split_bf16_enabled()) || d->tile == 23 || d->tile == 29) {
     const Halo9Plan h9 = halo9_plan(d);
-    if (h9.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h9.splits * h9.wk);
+    if (h9.ok) return slab_workspace_bytes((size_t)d->R * 9 * d->C, h9.splits * h9.wk) + ((h9.spec && d->dbias) ? (size_t)h9.splits * 4 * d->R * sizeof(double) : 0);
   }
   const Plan p = make_plan(d);
   if (p.splits <= 1) return 0;
@@ -1337,17 +1381,22 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     const Halo9Plan h9 = halo9_plan(d);
     if (h9.ok) {
       const size_t slab = (size_t)d->R * 9 * d->C;
-      const size_t need9 = slab_workspace_bytes(slab, h9.splits * h9.wk);
+      const size_t need_dw = slab_workspace_bytes(slab, h9.splits * h9.wk);
+      const bool fused_bias = h9.spec && d->dbias;
+      const size_t need9 = need_dw + (fused_bias ? (size_t)h9.splits * 4 * d->R * sizeof(double) : 0);
       QEA_REQUIRE(d->workspace && d->workspace_bytes >= need9 && ((uintptr_t)d->workspace & 15) == 0,
                   "qea_conv_wgrad: workspace of %zu bytes required, %zu given", need9, (size_t)d->workspace_bytes);
+      QEA_REQUIRE(!d->dbias || h9.spec, "qea_conv_wgrad: dbias is taken by the producer / consumer nine-tap form only (ask qea_conv_wgrad_fuses_bias first)");
       hipStream_t hs = (hipStream_t)stream;
       qea_prof_begin(QEA_PROF_CONV_WGRAD, hs);
-      rc = launch_halo9(d, h9, hs);
+      double* bias_ws = fused_bias ? reinterpret_cast<double*>(reinterpret_cast<char*>(d->workspace) + need_dw) : nullptr;
+      rc = launch_halo9(d, h9, hs, bias_ws);
       if (rc != QEA_OK) {
         qea_prof_abort(QEA_PROF_CONV_WGRAD);
         return rc;
       }
       reduce_slabs((float*)d->workspace, d->dw, (long long)slab / 4, h9.splits * h9.wk, d->accumulate, hs);
+      if (fused_bias) hipLaunchKernelGGL(bias_finalize_kernel, dim3(qea_cdiv(d->R, 4)), dim3(256), 0, hs, (const double*)bias_ws, h9.splits * 4, d->R, d->dbias, d->accumulate);
       qea_prof_end(QEA_PROF_CONV_WGRAD, hs, 2.0 * d->B * d->PH * (double)d->PW * (double)slab,
                    4.0 * ((double)d->B * d->PH * d->PW * d->R + (double)d->B * d->QH * d->QW * d->C + (double)slab),
                    (d->p_absmax && d->q_absmax) ? 2 : 1);
@@ -1356,6 +1405,7 @@ extern "C" int qea_conv_wgrad(const qea_wgrad_desc* d, void* stream) {
     }
     QEA_REQUIRE(d->tile == 0, "qea_conv_wgrad: tile 23 (nine-tap split-bf16) needs a 3x3 pad-1 stride-1 conv, R,C multiples of 64, PW in {16, 32k}");
   }
+  QEA_REQUIRE(!d->dbias, "qea_conv_wgrad: dbias is taken by the producer / consumer nine-tap form only (ask qea_conv_wgrad_fuses_bias first)");
   const Plan p = make_plan(d);
   const size_t need = (p.splits > 1) ? slab_workspace_bytes((size_t)d->R * d->KH * d->KW * d->C, p.splits) : 0;
   QEA_REQUIRE(need == 0 || (d->workspace && d->workspace_bytes >= need && ((uintptr_t)d->workspace & 15) == 0),

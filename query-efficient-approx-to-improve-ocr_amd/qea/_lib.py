@@ -45,7 +45,7 @@ class WgradDesc(C.Structure):
         ("B", _i32), ("PH", _i32), ("PW", _i32), ("QH", _i32), ("QW", _i32), ("R", _i32), ("C", _i32),
         ("KH", _i32), ("KW", _i32), ("pad_h", _i32), ("pad_w", _i32), ("stride_h", _i32), ("stride_w", _i32),
         ("ldp", _i32), ("ldq", _i32), ("accumulate", _i32), ("splits", _i32), ("tile", _i32),
-        ("p_absmax", _fp), ("q_absmax", _fp),
+        ("p_absmax", _fp), ("q_absmax", _fp), ("dbias", _fp),
     ]
 
 

@@ -346,9 +346,10 @@ class CRNNEngine:
                            stat64=st[gi] if st is not None else None, relu_scale=coef[gi, 2], relu_shift=coef[gi, 3], amax=dy_amax)
             if param_grads:
                 def bn_conv_grads(dy_=dy_, name=name, src=src, cin=cin, M=M, dy_amax=dy_amax):
-                    ops.colsum(dy_, 512, M, 512, G[c + name + ".bias"], accumulate=True)
+                    # (the bias gradient = column sums of dy rides with the weight gradient's staging waves where the kernel has it)
                     ops.conv_wgrad(dy_, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=512, Cc=cin, KH=3, KW=3,
-                                   pad=(1, 1), ldp=512, ldq=cin, accumulate=True, p_amax=dy_amax, q_amax=amx.get(src))
+                                   pad=(1, 1), ldp=512, ldq=cin, accumulate=True, p_amax=dy_amax, q_amax=amx.get(src),
+                                   dbias=G[c + name + ".bias"])
                 side.run(bn_conv_grads, dy_)
             wt = ops.flip_transposed(P[c + name + ".weight"], 512, cin, 3, 3)
             da = torch.empty(M, cin, device=dev)
@@ -370,9 +371,9 @@ class CRNNEngine:
             src = {"conv4": "a3", "conv3": "p2", "conv2": "p1"}[name]
             if param_grads:
                 def conv_grads(dyc=dyc, name=name, src=src, cin=cin, cout=cout, M=M, h=h, w=w, dyc_amax=dyc_amax):
-                    ops.colsum(dyc, cout, M, cout, G[c + name + ".bias"], accumulate=True)
                     ops.conv_wgrad(dyc, acts[src], G[c + name + ".weight"], B=B, PH=h, PW=w, QH=h, QW=w, R=cout, Cc=cin, KH=3, KW=3,
-                                   pad=(1, 1), ldp=cout, ldq=cin, accumulate=True, p_amax=dyc_amax, q_amax=amx.get(src))
+                                   pad=(1, 1), ldp=cout, ldq=cin, accumulate=True, p_amax=dyc_amax, q_amax=amx.get(src),
+                                   dbias=G[c + name + ".bias"])
                 side.run(conv_grads, dyc)
             wt = ops.flip_transposed(P[c + name + ".weight"], cout, cin, 3, 3)
             dnext = torch.empty(M, cin, device=dev)

@@ -218,9 +218,11 @@ def conv_can_pool(*, B, H, W, Cin, N, kw, ldx, ldy, mask=None):
 
 
 def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride=(1, 1), ldp, ldq,
-               accumulate=False, splits=0, tile=0, p_amax=None, q_amax=None):
+               accumulate=False, splits=0, tile=0, p_amax=None, q_amax=None, dbias=None):
     """p_amax / q_amax: device scalars holding the abs-max of p / q when the caller has them (the two-way fp16 split of the
-    nine-tap kernel needs both); in "split_f16" mode a missing one is computed here (one pass over the tensor)."""
+    nine-tap kernel needs both); in "split_f16" mode a missing one is computed here (one pass over the tensor).
+    dbias [R]: the bias gradient (column sums of p), same `accumulate`: inside the launch where the kernel has it (the producer /
+    consumer nine-tap form), else one colsum pass here."""
     L = _lib.lib()
     d = _lib.WgradDesc(p=_ptr(p), q=_ptr(q), dw=_ptr(dw), workspace=None, workspace_bytes=0,
                        B=B, PH=PH, PW=PW, QH=QH, QW=QW, R=R, C=Cc, KH=KH, KW=KW, pad_h=pad[0], pad_w=pad[1],
@@ -235,6 +237,11 @@ def conv_wgrad(p, q, dw, *, B, PH, PW, QH, QW, R, Cc, KH, KW, pad=(0, 0), stride
         if q_amax is None:
             q_amax = absmax(q, ldq, B * QH * QW, Cc)
         d.p_absmax, d.q_absmax = p_amax.data_ptr(), q_amax.data_ptr()
+    if dbias is not None:
+        if L.qea_conv_wgrad_fuses_bias(C.byref(d)):
+            d.dbias = dbias.data_ptr()
+        else:
+            colsum(p, ldp, B * PH * PW, R, dbias, accumulate=accumulate)
     need = L.qea_conv_wgrad_workspace_bytes(C.byref(d))
     if need:
         ws = workspace(need, p.device)

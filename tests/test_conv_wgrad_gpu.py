@@ -107,3 +107,32 @@ def test_wgrad_nine_tap_bit_reproducible_and_default():
         outs.append(dw.clone())
     assert torch.equal(outs[3], outs[4])
     assert (outs[3] - outs[0]).abs().max().item() <= 2e-6 * outs[0].abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,splits,acc", [(6, 8, 32, 128, 256, 0, False), (3, 4, 16, 256, 128, 3, True), (5, 16, 64, 64, 64, 1, True),
+                                                       (2, 8, 32, 64, 32, 0, True)])
+def test_wgrad_bias_gradient_rides_with_the_staging_waves(B, H, W, Cin, Cout, splits, acc):
+    """qea_wgrad_desc.dbias (ABI v8): the bias gradient = column sums of dY (nn.Conv2d(bias=True) under autograd,
+    models/model_crnn.py:38-45) from the producer waves of the producer / consumer nine-tap kernel — fp64 sums of what they stage,
+    one partial row per (split, wave), fixed-order reduction — against fp64 sums on the host; accumulate; a shape the kernel does not
+    take (32-wide blocks) gets the separate colsum pass through the same call; dW unchanged by the option."""
+    from qea import ops
+    g = torch.Generator().manual_seed(B * 7 + H)
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    dy = torch.randn(B, H, W, Cout, generator=g).cuda()
+    base = 0.25 if acc else float("nan")
+    dw0 = torch.full((Cout, 3, 3, Cin), base, device="cuda")
+    dw1 = dw0.clone()
+    db = torch.full((Cout,), base, device="cuda")
+    kw = dict(B=B, PH=H, PW=W, QH=H, QW=W, R=Cout, Cc=Cin, KH=3, KW=3, pad=(1, 1), ldp=Cout, ldq=Cin, accumulate=acc, splits=splits)
+    ops.conv_wgrad(dy, x, dw0, **kw)
+    ops.conv_wgrad(dy, x, dw1, dbias=db, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(dw0, dw1)
+    ref = dy.double().reshape(-1, Cout).sum(0).cpu() + (base if acc else 0.0)
+    err = (db.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * ref.abs().max().item() + 1e-6, err
+    # bit-reproducible
+    db2 = torch.full((Cout,), base, device="cuda")
+    ops.conv_wgrad(dy, x, dw1.fill_(base), dbias=db2, **kw)
+    assert torch.equal(db, db2)
