@@ -339,6 +339,15 @@ int qea_conv_c1_fwd(const float* x, const float* w, const float* bias, float* y,
  * Needs H % 2 == 0, W % 4 == 0, Co in {32, 64, 128}; absmax_pooled as qea_maxpool_fwd's absmax_out. */
 int qea_conv_c1_fwd_pool(const float* x, const float* w, const float* bias, float* y, int32_t ldy, float* pooled, int32_t ldp, int32_t B,
                          int32_t H, int32_t W, int32_t Co, int32_t relu, float* absmax_pooled, void* stream);
+/* ABI v8 (additive).  The whole backward of conv1 -> ReLU -> max_pool2d(2, 2) (models/model_crnn.py:37-38,47-48) from the POOLED tensor's
+ * gradient and the 1-channel input: the full-resolution activation is rebuilt from x (nine multiply-adds per element, the forward's own
+ * chain, so the pool's winners and the ReLU mask are the forward's bit for bit), neither it nor its gradient is read or written —
+ * qea_conv_c1_fwd_pool may therefore be given y = NULL.  dpool [B*(H/2)*(W/2)][lddp] is OVERWRITTEN with its ReLU-masked values;
+ * dw [Co][3][3], db [Co] (accumulate as in qea_conv_c1_wgrad; dw NULL: no parameter gradients), dx [B][H][W] (NULL: not wanted).
+ * Co = 64.  Same values as qea_maxpool_bwd(relu_mask) + qea_conv_c1_wgrad + qea_conv_c1_dgrad up to the order of the fp32 partial sums. */
+size_t qea_conv_c1_pool_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Co, int32_t need_dx);
+int qea_conv_c1_pool_bwd(const float* x, const float* w, const float* bias, float* dpool, int32_t lddp, float* dw, float* db, float* dx,
+                         int32_t B, int32_t H, int32_t W, int32_t Co, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 size_t qea_conv_c1_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Co);
 int qea_conv_c1_wgrad(const float* x, const float* dy, int32_t lddy, float* dw, float* db, int32_t B, int32_t H,
                       int32_t W, int32_t Co, int32_t accumulate, void* workspace, size_t workspace_bytes,

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd4_pool_kernel(const float* __r
           for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
         }
         o[r][j] = acc;
-        *reinterpret_cast<f32x4*>(y + ((row + r) * W + pw0 + j) * ldy + ct * 4) = acc;
+        if (y) *reinterpret_cast<f32x4*>(y + ((row + r) * W + pw0 + j) * ldy + ct * 4) = acc;
       }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -241,6 +241,202 @@ __global__ void conv_c1_wgrad_finalize_kernel(const float* __restrict__ ws, int 
     *d = accumulate ? *d + (float)s : (float)s;
   } else if (db) {
     db[co] = accumulate ? db[co] + (float)s : (float)s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 4 (ABI v8): the WHOLE backward of conv1 -> ReLU -> max_pool2d(2, 2) (models/model_crnn.py:37-38,47-48) from the pooled tensor's
+// gradient and the 1-channel INPUT alone.  The full-resolution activation a1 [B, 32, 128, 64] (2.1 GB at B = 2048) was written by the
+// forward only for this backward, read by qea_maxpool_bwd, whose 2.1 GB output (three quarters of it zeros) was then read by the
+// weight gradient and again by the input gradient: 2.4 ms of a step.  With C_in = 1 the activation costs nine multiply-adds per
+// element to rebuild from x (33 MB), so:
+//   c1_pool_route_kernel   one lane per 2 x 2 window: rebuilds the four pre-activations per channel with the forward's own fused
+//                          multiply-add chain (bias first, taps in kh, kw order: the bits the forward stored and pooled), picks the
+//                          winner as the pool did (first maximum in scan order, NaN wins), masks by the ReLU, overwrites the pooled
+//                          gradient with the masked value and leaves the winner's position (one byte per (window, channel)); for the
+//                          input gradient it also leaves T[tap][pixel] = sum_c dy[pixel][c] w[c][tap] (the per-tap channel sums of
+//                          conv_c1_dgrad_tile_kernel) for its four pixels;
+//   c1_pool_wgrad_kernel   one lane per channel walks windows: dW[c][tap] += g x[winner + tap], db[c] += g — the x patch of a window is
+//                          uniform across the wave (scalar loads), no cross-lane reduction;
+//   c1_pool_dx_kernel      dx[p] = sum over the nine taps of T[tap][p + (1 - kh, 1 - kw)].
+// ---------------------------------------------------------------------------------------------
+template <bool NEED_T>
+__global__ __launch_bounds__(256) void c1_pool_route_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ g, int ldg, unsigned* __restrict__ idx, float* __restrict__ T, int B,
+                                                            int H, int W) {
+  constexpr int Co = 64;
+  __shared__ __attribute__((aligned(16))) float Wl[Co * 12];      // [channel][9 taps, bias, 2 pad]
+  for (int e = threadIdx.x; e < Co * 12; e += 256) {
+    const int c = e / 12, t = e - c * 12;
+    Wl[e] = t < 9 ? w[c * 9 + t] : (t == 9 && bias ? bias[c] : 0.f);
+  }
+  __syncthreads();
+  const int OH = H >> 1, OW = W >> 1;
+  const long long NW = (long long)B * OH * OW;
+  const long long M = (long long)B * H * W;
+  for (long long wi = (long long)blockIdx.x * 256 + threadIdx.x; wi < NW; wi += (long long)gridDim.x * 256) {
+    const int ow = (int)(wi % OW);
+    const int oh = (int)((wi / OW) % OH);
+    const long long b = wi / ((long long)OW * OH);
+    const int wy = oh * 2, wx = ow * 2;
+    const float* xb = x + b * H * W;
+    float xp[4][4];                                                // x[wy - 1 .. wy + 2][wx - 1 .. wx + 2], zero outside the image
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int iy = wy + r - 1, ix = wx + c - 1;
+        xp[r][c] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xb[iy * W + ix] : 0.f;
+      }
+    float Tacc[4][9];
+    if (NEED_T) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) Tacc[j][t] = 0.f;
+    }
+    float* grow = g + wi * ldg;
+    unsigned* irow = idx + wi * (Co / 4);
+#pragma unroll 2
+    for (int c4 = 0; c4 < Co / 4; ++c4) {
+      f32x4 gv = *reinterpret_cast<const f32x4*>(grow + c4 * 4);
+      unsigned packed = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* wc = Wl + (c4 * 4 + k) * 12;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wc), w1 = *reinterpret_cast<const f32x4*>(wc + 4), w2 = *reinterpret_cast<const f32x4*>(wc + 8);
+        const float wt[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0]};
+        float m = -INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                              // scan order of the pool: (0,0), (0,1), (1,0), (1,1)
+          const int jr = j >> 1, jc = j & 1;
+          float acc = w2[1];                                       // bias first, then the taps in kh, kw order: the forward's chain
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc = __builtin_fmaf(wt[kh * 3 + kw], xp[jr + kh][jc + kw], acc);
+          const float v = fmaxf(acc, 0.f);
+          if (v > m || v != v) {
+            m = v;
+            arg = j;
+          }
+        }
+        const float gm = (m > 0.f) ? gv[k] : 0.f;                  // (qea_maxpool_bwd with relu_mask: a NaN winner routes nothing)
+        gv[k] = gm;
+        packed |= (unsigned)arg << (8 * k);
+        if (NEED_T) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float mj = (arg == j) ? gm : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) Tacc[j][t] = __builtin_fmaf(mj, wt[t], Tacc[j][t]);
+          }
+        }
+      }
+      *reinterpret_cast<f32x4*>(grow + c4 * 4) = gv;
+      irow[c4] = packed;
+    }
+    if (NEED_T) {
+      // T[tap][pixel]: consecutive lanes hold consecutive windows of a row -> pairs of floats 8 bytes apart: coalesced float2 stores
+      const long long p0 = (b * H + wy) * (long long)W + wx;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float* Tp = T + (long long)t * M;
+        *reinterpret_cast<float2*>(Tp + p0) = make_float2(Tacc[0][t], Tacc[1][t]);
+        *reinterpret_cast<float2*>(Tp + p0 + W) = make_float2(Tacc[2][t], Tacc[3][t]);
+      }
+    }
+  }
+}
+
+// ws[(block * 4 + wave)][tap * 64 + c] (tap 9 = bias): partial sums of one wave's windows; conv_c1_wgrad_finalize_kernel sums them in fp64.
+// A wave walks its windows FOUR AT A TIME (four neighbours of one window row: W / 2 is a multiple of 4): their 4 x 10 input patch is
+// uniform over the wave (scalar loads), the four gradient / winner loads of the NEXT group are in flight under this group's arithmetic
+// (one window per trip left every trip waiting for its own loads: 1.15 ms at B = 2048 against 0.2 ms of arithmetic).
+__global__ __launch_bounds__(256) void c1_pool_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g, int ldg,
+                                                            const unsigned char* __restrict__ idx, int B, int H, int W, int win_per_wave,
+                                                            float* __restrict__ ws) {
+  constexpr int Co = 64;
+  const int c = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int OH = H >> 1, OW = W >> 1;
+  const long long NW = (long long)B * OH * OW;
+  const long long w0 = ((long long)blockIdx.x * 4 + wave) * win_per_wave;   // (win_per_wave is a multiple of 4)
+  long long w1 = w0 + win_per_wave;
+  if (w1 > NW) w1 = NW;
+  float acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+  float gq[4];
+  int aq[4];
+  auto load_group = [&](long long wi, float* gv, int* av) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gv[k] = g[(wi + k) * ldg + c];
+      av[k] = idx[(wi + k) * Co + c];
+    }
+  };
+  if (w0 < w1) load_group(w0, gq, aq);
+  for (long long wi = w0; wi < w1; wi += 4) {                      // (uniform over the wave)
+    float gn[4] = {0.f, 0.f, 0.f, 0.f};
+    int an[4] = {0, 0, 0, 0};
+    if (wi + 4 < w1) load_group(wi + 4, gn, an);
+    const int ow = (int)(wi % OW);
+    const int oh = (int)((wi / OW) % OH);
+    const long long b = wi / ((long long)OW * OH);
+    const int wy = oh * 2, wx = ow * 2;
+    const float* xb = x + b * H * W;
+    float xr[4][10];                                               // rows wy - 1 .. wy + 2, columns wx - 1 .. wx + 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 10; ++cc) {
+        const int iy = wy + r - 1, ix = wx + cc - 1;
+        xr[r][cc] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xb[iy * W + ix] : 0.f;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gm = gq[k];
+      const int arg = aq[k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float mj = (arg == j) ? gm : 0.f;
+        const int jr = j >> 1, jc = j & 1;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = __builtin_fmaf(mj, xr[jr + kh][2 * k + jc + kw], acc[kh * 3 + kw]);
+      }
+      acc[9] += gm;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gq[k] = gn[k];
+      aq[k] = an[k];
+    }
+  }
+  float* o = ws + ((size_t)blockIdx.x * 4 + wave) * 10 * Co;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) o[t * Co + c] = acc[t];
+}
+
+__global__ void c1_pool_dx_kernel(const float* __restrict__ T, float* __restrict__ dx, int B, int H, int W, int accumulate) {
+  const long long M = (long long)B * H * W;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < M; p += (long long)gridDim.x * blockDim.x) {
+    const int px = (int)(p % W);
+    const int py = (int)((p / W) % H);
+    float s = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int qy = py + 1 - kh;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int qx = px + 1 - kw;
+        if ((unsigned)qy < (unsigned)H && (unsigned)qx < (unsigned)W) s += T[(long long)(kh * 3 + kw) * M + p + (long long)(1 - kh) * W + (1 - kw)];
+      }
+    }
+    dx[p] = accumulate ? dx[p] + s : s;
   }
 }
 
@@ -450,7 +646,7 @@ extern "C" int qea_conv_c1_fwd(const float* x, const float* w, const float* bias
 
 extern "C" int qea_conv_c1_fwd_pool(const float* x, const float* w, const float* bias, float* y, int32_t ldy, float* pooled, int32_t ldp, int32_t B,
                                     int32_t H, int32_t W, int32_t Co, int32_t relu, float* absmax_pooled, void* stream) {
-  QEA_REQUIRE(x && w && y && pooled && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 4 == 0 && (Co == 32 || Co == 64 || Co == 128) && ldy % 4 == 0 &&
+  QEA_REQUIRE(x && w && pooled && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 4 == 0 && (Co == 32 || Co == 64 || Co == 128) && ldy % 4 == 0 &&
                   ldy >= Co && ldp % 4 == 0 && ldp >= Co && (long long)B * H * W < 0x7fffffffLL,
               "qea_conv_c1_fwd_pool: needs H %% 2 == 0, W %% 4 == 0, Co in {32, 64, 128}, fewer than 2^31 pixels");
   QEA_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)pooled & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), "qea_conv_c1_fwd_pool: 16-byte alignment");
@@ -500,6 +696,59 @@ extern "C" int qea_conv_c1_wgrad(const float* x, const float* dy, int32_t lddy, 
   hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(grid), dim3(256), lds, s, x, dy, lddy, B, H, W, Co, rt, rpt, (float*)workspace);
   hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(qea_cdiv(10 * Co, 4)), dim3(256), 0, s, (const float*)workspace, grid, Co, dw, db,
                      accumulate);
+  QEA_CHECK_LAUNCH();
+  return QEA_OK;
+}
+
+// workspace: [winner bytes: B*(H/2)*(W/2)*64, rounded up to 256][T: 9*B*H*W floats when dx is wanted][wgrad partials: blocks*4 rows of 640 floats]
+static long long c1pb_win_per_wave(long long NW) {
+  long long wpw = (NW + 4 * 2048 - 1) / (4 * 2048);                // about 2048 workgroups of four waves
+  wpw = wpw < 16 ? 16 : wpw;
+  return (wpw + 3) & ~3LL;                                         // whole groups of four windows
+}
+
+extern "C" size_t qea_conv_c1_pool_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Co, int32_t need_dx) {
+  if (B <= 0 || H <= 0 || W <= 0 || Co != 64 || H % 2 || W % 8) return 0;
+  const long long NW = (long long)B * (H / 2) * (W / 2);
+  const long long wpw = c1pb_win_per_wave(NW);
+  const long long blocks = (NW + 4 * wpw - 1) / (4 * wpw);
+  size_t b = ((size_t)NW * 64 + 255) & ~(size_t)255;
+  if (need_dx) b += (size_t)9 * B * H * W * sizeof(float);
+  b += (size_t)blocks * 4 * 640 * sizeof(float);
+  return b;
+}
+
+extern "C" int qea_conv_c1_pool_bwd(const float* x, const float* w, const float* bias, float* dpool, int32_t lddp, float* dw, float* db, float* dx,
+                                    int32_t B, int32_t H, int32_t W, int32_t Co, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  QEA_REQUIRE(x && w && dpool && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 8 == 0 && Co == 64 && lddp % 4 == 0 && lddp >= Co &&
+                  ((uintptr_t)dpool & 15) == 0 && ((uintptr_t)x & 7) == 0 && (long long)B * H * W < 0x7fffffffLL,
+              "qea_conv_c1_pool_bwd: needs Co == 64, even H, W %% 8 == 0, 16-byte aligned dpool rows, fewer than 2^31 pixels");
+  const size_t need = qea_conv_c1_pool_bwd_workspace_bytes(B, H, W, Co, dx != nullptr);
+  QEA_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0, "qea_conv_c1_pool_bwd: workspace of %zu bytes (256-byte aligned) required", need);
+  const long long NW = (long long)B * (H / 2) * (W / 2);
+  const long long wpw = c1pb_win_per_wave(NW);
+  const long long blocks = (NW + 4 * wpw - 1) / (4 * wpw);
+  char* wsb = (char*)workspace;
+  unsigned* idx = (unsigned*)wsb;
+  wsb += ((size_t)NW * 64 + 255) & ~(size_t)255;
+  float* T = nullptr;
+  if (dx) {
+    T = (float*)wsb;
+    wsb += (size_t)9 * B * H * W * sizeof(float);
+  }
+  float* part = (float*)wsb;
+  hipStream_t s = (hipStream_t)stream;
+  const int rgrid = grid_for(NW, 8192);
+  if (dx) hipLaunchKernelGGL(c1_pool_route_kernel<true>, dim3(rgrid), dim3(256), 0, s, x, w, bias, dpool, lddp, idx, T, B, H, W);
+  else hipLaunchKernelGGL(c1_pool_route_kernel<false>, dim3(rgrid), dim3(256), 0, s, x, w, bias, dpool, lddp, idx, T, B, H, W);
+  if (dw) {
+    hipLaunchKernelGGL(c1_pool_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (const float*)dpool, lddp, (const unsigned char*)idx, B, H, W,
+                       (int)wpw, part);
+    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(qea_cdiv(10 * Co, 4)), dim3(256), 0, s, (const float*)part, (int)(blocks * 4), Co, dw, db,
+                       accumulate);
+  }
+  if (dx) hipLaunchKernelGGL(c1_pool_dx_kernel, dim3(grid_for((long long)B * H * W, 8192)), dim3(256), 0, s, (const float*)T, dx, B, H, W, 0);
   QEA_CHECK_LAUNCH();
   return QEA_OK;
 }

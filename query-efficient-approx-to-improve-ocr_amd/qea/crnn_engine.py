@@ -23,6 +23,8 @@ CONVS = (("conv2", 64, 128, True, (2, 2)), ("conv3", 128, 256, True, None), ("co
 
 
 FUSE_POOL_BWD = True  # tests flip this: conv6's (2,1) pool backward inside BatchNorm2's backward (qea_bn_bwd_pool)
+FUSE_C1_BWD = True    # tests flip this: conv1 -> ReLU -> pool backward from the pooled gradient and x alone (qea_conv_c1_pool_bwd)
+KEEP_A1 = False       # tests set this: keep conv1's full-resolution activation (2.1 GB at B = 2048) although nothing in the product reads it
 
 class CRNNEngine:
     def __init__(self, module, vocab):
@@ -65,16 +67,20 @@ class CRNNEngine:
         slot = (lambda: pool_.slot()) if pool_ is not None else (lambda: None)
         amx = {}
         # conv1 (C_in = 1) + ReLU, pool 2x2
-        a1 = torch.empty(B * H * W, 64, device=dev)
+        # (round 4: the backward rebuilds this activation from x, qea_conv_c1_pool_bwd — it is written only where something still reads it)
+        keep_a1 = KEEP_A1 or (need_grad and not (FUSE_POOL and FUSE_C1_BWD)) or H % 2 or W % 8
+        a1 = torch.empty(B * H * W, 64, device=dev) if keep_a1 else None
         h, w = H // 2, W // 2
         p1 = torch.empty(B * h * w, 64, device=dev)
         amx["p1"] = slot()
         # conv1 + ReLU + max-pool in one pass where the shape allows (FUSE_POOL; the same bits as the two launches)
         if not (FUSE_POOL and ops.conv_c1_fwd_pool(x, P[c + "conv1.weight"], P[c + "conv1.bias"], a1, 64, p1, 64, B, H, W, 64, relu=True,
                                                    pooled_amax=amx["p1"])):
+            if a1 is None:
+                a1 = torch.empty(B * H * W, 64, device=dev)
             ops.conv_c1_fwd(x, P[c + "conv1.weight"], P[c + "conv1.bias"], a1, 64, B, H, W, 64, relu=True)
             ops.maxpool_fwd(a1, 64, p1, 64, B, H, W, 64, 2, 2, amax=amx["p1"])
-        acts = {"a1": a1, "p1": p1}
+        acts = {"a1": a1, "p1": p1}                       # a1 None: not kept (the backward rebuilds it from x; tests: ctx["conv1_params"])
         cur, ccur, cur_name = p1, 64, "p1"
         dims = {"conv1": (H, W)}
         for name, cin, cout, relu, pool in CONVS:
@@ -186,7 +192,7 @@ class CRNNEngine:
         ops.log_softmax_fwd(logits, vp, lp, vp, T * B, self.vocab)
         out = lp.view(T, B, vp)[:, :, :self.vocab]
         if need_grad:
-            ctx.update(acts=acts, dims=dims, lstm=lstm, lp=lp, T=T, h6=h6, w6=w6, amx=amx)
+            ctx.update(acts=acts, dims=dims, lstm=lstm, lp=lp, T=T, h6=h6, w6=w6, amx=amx, conv1_params=(P[c + "conv1.weight"], P[c + "conv1.bias"]))
         return out, ctx
 
     # ------------------------------------------------------------------ backward
@@ -385,15 +391,27 @@ class CRNNEngine:
                            x_amax=dyc_amax, y_amax=dnext_amax)
             dcur, dcur_amax = dnext, dnext_amax
         # dcur = grad of p1 [B,16,W/2,64]; conv1
-        dy1 = torch.empty(B * H * W, 64, device=dev)
-        ops.maxpool_bwd(acts["a1"], 64, dcur, 64, dy1, 64, B, H, W, 64, 2, 2, relu_mask=True)
-        if param_grads:
-            side.run(lambda: ops.conv_c1_wgrad(ctx["x"], dy1, 64, G[c + "conv1.weight"], G[c + "conv1.bias"], B, H, W, 64, accumulate=True),
-                     dy1)
         dx = None
-        if need_dx:
-            dx = torch.empty(B, 1, H, W, device=dev)
-            ops.conv_c1_dgrad(dy1, 64, P[c + "conv1.weight"], dx, B, H, W, 64)
+        if FUSE_C1_BWD and H % 2 == 0 and W % 8 == 0 and (param_grads or need_dx):
+            # conv1 -> ReLU -> pool backward from the pooled gradient and the 1-channel input: the activation is rebuilt (nine multiply-adds
+            # per element), neither it nor its 2.1 GB gradient is read or written (dcur is overwritten with its masked values)
+            if need_dx:
+                dx = torch.empty(B, 1, H, W, device=dev)
+            ops.conv_c1_pool_bwd(ctx["x"], P[c + "conv1.weight"], P[c + "conv1.bias"], dcur, 64, G[c + "conv1.weight"] if param_grads else None,
+                                 G[c + "conv1.bias"] if param_grads else None, dx, B, H, W, 64, accumulate=True)
+        else:
+            a1 = acts["a1"]
+            if a1 is None:                                  # (not kept by the forward: rebuild it)
+                a1 = torch.empty(B * H * W, 64, device=dev)
+                ops.conv_c1_fwd(ctx["x"], P[c + "conv1.weight"], P[c + "conv1.bias"], a1, 64, B, H, W, 64, relu=True)
+            dy1 = torch.empty(B * H * W, 64, device=dev)
+            ops.maxpool_bwd(a1, 64, dcur, 64, dy1, 64, B, H, W, 64, 2, 2, relu_mask=True)
+            if param_grads:
+                side.run(lambda: ops.conv_c1_wgrad(ctx["x"], dy1, 64, G[c + "conv1.weight"], G[c + "conv1.bias"], B, H, W, 64, accumulate=True),
+                         dy1)
+            if need_dx:
+                dx = torch.empty(B, 1, H, W, device=dev)
+                ops.conv_c1_dgrad(dy1, 64, P[c + "conv1.weight"], dx, B, H, W, 64)
         side.join()
         if full is not None and dx is not None:
             Bf, g, k = full[0], ctx["_g"], B

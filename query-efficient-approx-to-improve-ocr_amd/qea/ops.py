@@ -480,6 +480,16 @@ def maxpool_fwd(x, ldx, y, ldy, B, H, W, C_, kh, kw, amax=None):
     _lib.check(_lib.lib().qea_maxpool_fwd(_ptr(x), ldx, _ptr(y), ldy, B, H, W, C_, kh, kw, _ptr(amax), _stream()), "qea_maxpool_fwd")
 
 
+def conv_c1_pool_bwd(x, w, bias, dpool, lddp, dw, db, dx, B, H, W, Co, accumulate=False):
+    """backward of conv1 -> ReLU -> max_pool2d(2, 2) from the pooled tensor's gradient and the 1-channel input (ABI v8): dpool is overwritten
+    with its ReLU-masked values; dw / db (None: no parameter gradients), dx (None: not wanted)."""
+    L = _lib.lib()
+    need = L.qea_conv_c1_pool_bwd_workspace_bytes(B, H, W, Co, int(dx is not None))
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=x.device)
+    _lib.check(L.qea_conv_c1_pool_bwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(dpool), lddp, _ptr(dw), _ptr(db), _ptr(dx), B, H, W, Co, int(accumulate),
+                                      ws.data_ptr(), ws.numel(), _stream()), "qea_conv_c1_pool_bwd")
+
+
 def maxpool_bwd(x, ldx, dy, lddy, dx, lddx, B, H, W, C_, kh, kw, relu_mask=False, accumulate=False, amax=None):
     _lib.check(_lib.lib().qea_maxpool_bwd(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, B, H, W, C_, kh, kw,
                                           int(relu_mask), int(accumulate), _ptr(amax), _stream()), "qea_maxpool_bwd")

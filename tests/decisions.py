@@ -76,7 +76,15 @@ def hip_crnn_trace(saved, first=None, start=0):
     force, taps = {}, {}
     for k in "123456":
         h, w = dims["conv" + k]
-        act = _nchw(acts["a" + k], B, h, w, b0)
+        a = acts["a" + k]
+        if a is None and k == "1":
+            # conv1's activation is not kept by the product (its backward rebuilds it from x): rebuild it the same way for the trace
+            from qea import ops
+            wt, bs = saved["conv1_params"]
+            xin = saved["x"]
+            a = torch.empty(xin.shape[0] * H * W, 64, device=xin.device)
+            ops.conv_c1_fwd(xin, wt.detach(), bs.detach(), a, 64, xin.shape[0], H, W, 64, relu=True)
+        act = _nchw(a, B, h, w, b0)
         taps["convo.relu" + k] = act
         force["convo.relu" + k] = act > 0
         if "convo.pool" + k in mo.POOL_SITES:

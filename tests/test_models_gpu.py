@@ -622,6 +622,66 @@ def test_crnn_fused_pools_are_bit_identical():
         assert all(torch.equal(u, v) for u, v in zip(*res))
 
 
+def test_conv1_relu_pool_backward_from_the_pooled_gradient():
+    """qea_conv_c1_pool_bwd (ABI v8): conv1 -> ReLU -> max_pool2d(2, 2) backward (models/model_crnn.py:37-38,47-48 under autograd) from the
+    pooled tensor's gradient and the 1-channel input alone — the activation rebuilt with the forward's own multiply-add chain — against
+    qea_conv_c1_fwd + qea_maxpool_bwd(relu_mask) + qea_conv_c1_wgrad + qea_conv_c1_dgrad: (i) kernel level incl. windows of equal
+    activations (first in scan order wins), all-negative windows and image borders: the masked pooled gradient equals the window sums of
+    the routed gradient BIT FOR BIT (same winners, same mask), dW / db / dx to fp32 summation order; (ii) through the CRNN with the
+    engine's switch, with and without the input gradient, and with the activation kept or not."""
+    from models.model_crnn import CRNN
+    from oracle import model_oracle as mo
+    from qea import crnn_engine, ops
+    g = torch.Generator().manual_seed(11)
+    B, Hh, Ww, Co = 5, 32, 128, 64
+    x = torch.rand(B, 1, Hh, Ww, generator=g)
+    x[0, 0, :8, :16] = 0.5                                             # constant patch: four equal activations per window
+    x[1, 0, 8:16, 32:64] = 0.0
+    x = x.cuda()
+    w = (torch.randn(Co, 1, 3, 3, generator=g) * 0.4).cuda()
+    b = (torch.randn(Co, generator=g) * 0.2).cuda()
+    b[:8] = -5.0                                                       # channels whose activations are all zero
+    dpool = torch.randn(B * (Hh // 2) * (Ww // 2), Co, generator=g).cuda()
+    M = B * Hh * Ww
+    a1 = torch.empty(M, Co, device="cuda")
+    ops.conv_c1_fwd(x, w, b, a1, Co, B, Hh, Ww, Co, relu=True)
+    dy1 = torch.empty(M, Co, device="cuda")
+    ops.maxpool_bwd(a1, Co, dpool, Co, dy1, Co, B, Hh, Ww, Co, 2, 2, relu_mask=True)
+    dw0, db0 = torch.zeros(Co, 1, 3, 3, device="cuda"), torch.zeros(Co, device="cuda")
+    ops.conv_c1_wgrad(x, dy1, Co, dw0, db0, B, Hh, Ww, Co)
+    dx0 = torch.empty(B, 1, Hh, Ww, device="cuda")
+    ops.conv_c1_dgrad(dy1, Co, w, dx0, B, Hh, Ww, Co)
+    for need_dx in (True, False):
+        gm = dpool.clone()
+        dw1, db1 = torch.full((Co, 1, 3, 3), 0.5, device="cuda"), torch.full((Co,), 0.5, device="cuda")
+        dx1 = torch.empty(B, 1, Hh, Ww, device="cuda") if need_dx else None
+        ops.conv_c1_pool_bwd(x, w, b, gm, Co, dw1, db1, dx1, B, Hh, Ww, Co, accumulate=True)
+        torch.cuda.synchronize()
+        wsum = dy1.view(B, Hh // 2, 2, Ww // 2, 2, Co).sum(dim=(2, 4)).reshape(-1, Co)      # one non-zero per window: an exact sum
+        assert torch.equal(gm, wsum)
+        assert ((dw1 - 0.5) - dw0).abs().max().item() <= 2e-5 * dw0.abs().max().item()
+        assert ((db1 - 0.5) - db0).abs().max().item() <= 2e-5 * db0.abs().max().item()
+        if need_dx:
+            assert (dx1 - dx0).abs().max().item() <= 2e-5 * dx0.abs().max().item()
+    res = []
+    try:
+        for fuse, keep in ((True, False), (True, True), (False, False)):
+            crnn_engine.FUSE_C1_BWD, crnn_engine.KEEP_A1 = fuse, keep
+            crnn = _load(CRNN(95, False), mo.crnn_state_shapes, 3).train()
+            xi = H.synth_images(5, 41).cuda().requires_grad_(True)
+            lp = crnn(xi)
+            assert (lp.grad_fn.saved["acts"]["a1"] is None) == (fuse and not keep)
+            (lp * torch.linspace(0.5, 1.5, lp.numel(), device="cuda").view_as(lp)).sum().backward()
+            res.append([p.grad.clone() for p in crnn.parameters()] + [xi.grad.clone()])
+    finally:
+        crnn_engine.FUSE_C1_BWD, crnn_engine.KEEP_A1 = True, False
+    for other in res[1:]:
+        for u, v in zip(res[0], other):
+            den = v.double().norm().item()
+            if den > 0:
+                assert (u.double() - v.double()).norm().item() / den <= 2e-6
+
+
 def test_pool_backward_inside_the_bn_backward():
     """qea_bn_bwd_pool (ABI v8): the max-pool backward + the skip path's sum rebuilt per window inside the two passes of the BatchNorm
     backward (models/model_unet.py:52-59, models/model_crnn.py:53-54 under autograd) against qea_maxpool_bwd(accumulate) followed by
