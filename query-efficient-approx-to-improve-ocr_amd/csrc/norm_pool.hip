@@ -725,10 +725,16 @@ extern "C" int qea_bn_bwd_pool(const float* da, int32_t ldda, const float* dpool
   QEA_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && (kw == 1 || kw == 2) && W % kw == 0, "qea_bn_bwd_pool: 2 x kw windows, kw in {1, 2}, H and W multiples");
   const long long M = (long long)B * H * W;
   const long long NWIN = M / (2 * kw);
-  const ColGeom g = col_geom(NWIN, C);
+  // (a window is 2 * kw rows of work: the reduction's blocks are sized as for that many rows, so that a small tensor — the reference's own
+  // batch sizes — still spreads over the chip instead of walking its windows in 16 workgroups)
+  ColGeom g = col_geom(M, C);
+  g.rows_per_block = (g.rows_per_block + 2 * kw - 1) / (2 * kw);
+  if (g.rows_per_block < 1) g.rows_per_block = 1;
+  g.grid = (int)((NWIN + g.rows_per_block - 1) / g.rows_per_block);
   int rc = check_nc("qea_bn_bwd_pool", M, C, workspace_bytes, workspace, g);
   if (rc) return rc;
-  QEA_REQUIRE(workspace_bytes >= qea_colreduce_workspace_bytes(M, C), "qea_bn_bwd_pool: workspace too small (qea_colreduce_workspace_bytes(B * H * W, C))");
+  QEA_REQUIRE(workspace_bytes >= qea_colreduce_workspace_bytes(M, C) && g.grid <= col_geom(M, C).grid,
+              "qea_bn_bwd_pool: workspace too small (qea_colreduce_workspace_bytes(B * H * W, C))");
   QEA_REQUIRE(ldy % 4 == 0 && lddy % 4 == 0 && lddp % 4 == 0 && (!da || ldda % 4 == 0), "qea_bn_bwd_pool: strides must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
   double* ws = (double*)workspace;

@@ -70,12 +70,13 @@ class PhaseBGraphs:
         if n < self.eager_steps:
             return None
         cap = self._cap(labels)
+        lr = float(t.optimizer_prep.param_groups[0]["lr"])          # baked into the captured Adam launch
         key = None
         for k in self.graphs:
-            if k[:3] == shape and k[3] >= cap and (key is None or k[3] < key[3]):
+            if k[:3] == shape and k[4] == lr and k[3] >= cap and (key is None or k[3] < key[3]):
                 key = k
         if key is None:
-            key = shape + (cap,)
+            key = shape + (cap, lr)
             self.graphs[key] = self._capture(X, key)
         g = self.graphs[key]
         g["X"].copy_(X)
@@ -90,7 +91,7 @@ class PhaseBGraphs:
 
     def _capture(self, X, key):
         t = self.t
-        B, Hh, W, L = key
+        B, Hh, W, L, _lr = key
         dev = X.device
         st = {"X": torch.empty_like(X), "y": torch.zeros(B * L, dtype=torch.int32, device=dev),
               "ysz": torch.ones(B, dtype=torch.int32, device=dev)}
@@ -106,6 +107,70 @@ class PhaseBGraphs:
             loss.backward()
             t._step_prep()
             return loss.detach(), scores.detach(), img.detach()
+
+        st["step"] = GraphedStep(fn, warmup=0)
+        return st
+
+
+class PhaseAGraphs:
+    """The CRNN side of Phase A of the area trainer (train_nn_area.py:237-275: CRNN forward on the R jittered copies of the k picked strips,
+    CTC against the black box's labels of the LAST copy, backward of that copy, Adam(CRNN)) as one hipGraph per (k, R, width, target cap).
+    The jitter (its Philox seed and call counter are kernel arguments) and the black box (a host call) stay outside: the graph starts from
+    the noisy strips.  Same warm-up rule and capturable-Adam requirement as PhaseBGraphs."""
+
+    def __init__(self, trainer, eager_steps=2):
+        self.t = trainer
+        self.eager_steps = eager_steps
+        self.seen = {}
+        self.graphs = {}
+
+    def step(self, noisy, labels_last, R):
+        """noisy [R*k,1,H,W] (device, replica-major), labels_last: the k black-box labels of the last replica.  Returns the loss (device
+        scalar) after the graph has run the backward and the CRNN update, or None when the step has to run eagerly."""
+        t = self.t
+        RK, _, Hh, W = noisy.shape
+        shape = (RK, R, Hh, W)
+        n = self.seen.get(shape, 0)
+        self.seen[shape] = n + 1
+        if n < self.eager_steps:
+            return None
+        k = RK // R
+        cap = ((max(1, max(len(l) for l in labels_last)) + 7) // 8) * 8
+        lr = float(t.optimizer_crnn.param_groups[0]["lr"])          # baked into the captured Adam launch: a scheduler step means a new graph
+        key = None
+        for kk in self.graphs:
+            if kk[:4] == shape and kk[5] == lr and kk[4] >= cap and (key is None or kk[4] < key[4]):
+                key = kk
+        if key is None:
+            key = shape + (cap, lr)
+            self.graphs[key] = self._capture(noisy, key)
+        g = self.graphs[key]
+        g["X"].copy_(noisy)
+        L = key[4]
+        y = torch.zeros(k * L, dtype=torch.int32)
+        flat = [t.char_to_index[c] for c in "".join(labels_last)]
+        y[:len(flat)] = torch.tensor(flat, dtype=torch.int32)
+        g["y"].copy_(y)
+        g["ysz"].copy_(torch.tensor([len(l) for l in labels_last], dtype=torch.int32))
+        return g["step"]()
+
+    def _capture(self, noisy, key):
+        t = self.t
+        RK, R, Hh, W, L, _lr = key
+        k = RK // R
+        dev = noisy.device
+        st = {"X": torch.empty_like(noisy), "y": torch.zeros(k * L, dtype=torch.int32, device=dev), "ysz": torch.ones(k, dtype=torch.int32, device=dev)}
+        ctc = type(t.primary_loss_fn)()
+        ctc.max_target_length = L
+
+        def fn():
+            t.crnn_model.zero_grad()
+            scores = t.crnn_model(st["X"], replica_groups=R, backward_group=R - 1)
+            pred = torch.full((k,), scores.shape[0], dtype=torch.int32, device=dev)
+            loss = ctc(scores[:, (R - 1) * k:, :], st["y"], pred, st["ysz"])
+            loss.backward()
+            t._step_crnn()
+            return loss.detach()
 
         st["step"] = GraphedStep(fn, warmup=0)
         return st

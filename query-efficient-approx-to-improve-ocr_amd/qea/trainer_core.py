@@ -75,6 +75,24 @@ def _logger():
         return _NullLogger()
 
 
+class GraphedLoss:
+    """A loss whose backward and optimiser step already ran inside a hipGraph replay (qea.graph.PhaseAGraphs): .item() reads it,
+    .backward() and multiplication by the data-parallel share are no-ops the caller may still perform."""
+    graphed = True
+
+    def __init__(self, value):
+        self.value = value
+
+    def item(self):
+        return float(self.value.item())
+
+    def backward(self):
+        return None
+
+    def __mul__(self, _):
+        return self
+
+
 class TrainerCore:
     """Everything the two TrainNNPrep classes share.  Attribute names follow the reference's."""
 
@@ -130,14 +148,16 @@ class TrainerCore:
         self.secondary_loss_fn = torch.nn.MSELoss().to(self.device)
         # [new] --graph: Phase B replayed as a hipGraph (qea.graph.PhaseBGraphs); needs Adam's step count on the device
         self.phase_b_graphs = None
+        self.phase_a_graphs = None
         adam_kw = {}
         if getattr(args, "graph", False) and self.world == 1 and self.device.type == "cuda" and self.backend.gpu_jitter:
             adam_kw = {"capturable": True}
         self.optimizer_crnn = B.Adam(self.crnn_model.parameters(), lr=self.lr_crnn, weight_decay=weight_decay, **adam_kw)
         self.optimizer_prep = B.Adam(self.prep_model.parameters(), lr=self.lr_prep, weight_decay=weight_decay, **adam_kw)
         if adam_kw:
-            from qea.graph import PhaseBGraphs
+            from qea.graph import PhaseAGraphs, PhaseBGraphs
             self.phase_b_graphs = PhaseBGraphs(self)
+            self.phase_a_graphs = PhaseAGraphs(self)
 
     def _make_sampler(self, needs_cers):
         from selection_utils import datasampler_factory
@@ -181,6 +201,12 @@ class TrainerCore:
         if self.backend.gpu_jitter and imgs.is_cuda and R > 1:
             noisy, _ = noiser.batch(imgs, replicas=R)
             ocr_labels = self.ocr.get_labels(noisy.cpu())
+            if last_only and self.phase_a_graphs is not None and self.world == 1:
+                # [new] --graph: CRNN forward on the R copies, CTC of the last copy, its backward and Adam(CRNN) as ONE hipGraph replay; the
+                # caller sees a loss that is already back-propagated and applied (GraphedLoss)
+                done = self.phase_a_graphs.step(noisy, ocr_labels[(R - 1) * k:], R)
+                if done is not None:
+                    return [GraphedLoss(done)], R * k
             # last_only (area flow): only the last replica's loss is back-propagated -> its samples are the only ones the backward visits
             scores = self.crnn_model(noisy, replica_groups=R, backward_group=R - 1 if last_only else None)
             out_size = torch.tensor([scores.shape[0]] * k, dtype=torch.int)

@@ -152,8 +152,9 @@ class TrainNNPrep(TrainerCore):
                         loss = rep_losses[-1]
                     if self.inner_limit:
                         CRNN_training_loss = loss.item() / max(1, self.inner_limit)
-                        (loss * share if share != 1.0 else loss).backward()   # the last replica only, as the reference (:269-271)
-                        self._step_crnn()
+                        if not getattr(loss, "graphed", False):    # ([new] --graph: backward and Adam(CRNN) ran inside the replay)
+                            (loss * share if share != 1.0 else loss).backward()   # the last replica only, as the reference (:269-271)
+                            self._step_crnn()
                 # ---------------- Phase B ----------------
                 replayed = self.phase_b_graphs.step(X_var, labels) if self.phase_b_graphs is not None else None
                 if replayed is not None:                         # [new] --graph: the same step as one hipGraph replay

@@ -132,6 +132,32 @@ def test_patch_trainer_docs_per_step_batches_phase_a(tmp_path):
     assert d <= 1e-4, d
 
 
+def test_area_trainer_graph_replays_both_phases(tmp_path):
+    """[new] --graph with Phase A on: the CRNN side of Phase A (forward on the R jittered copies, CTC of the last copy, backward, Adam(CRNN))
+    and Phase B each as one hipGraph replay per shape equal the eager loop: same CRNN and cleaner weights after six steps (the jitter's
+    sigma draws and Philox counters follow the same sequence in both runs)."""
+    from datasets.synthetic import SyntheticTextAreas
+    from train_nn_area import TrainNNPrep
+    res = {}
+    for flag in (False, True):
+        torch.manual_seed(0)
+        import random
+        random.seed(0)
+        tr = SyntheticTextAreas(48, seed=1, include_name=True, include_index=True)
+        cers_path = tmp_path / f"cers{int(flag)}.json"
+        json.dump({n: (i % 7) / 6 for i, n in enumerate(tr.names)}, open(cers_path, "w"))
+        args = _args("a", tmp_path / f"exp{int(flag)}", batch_size=8, inner_limit=2, minibatch_subset="topKCER", minibatch_subset_prop=0.5,
+                     cers_ocr_path=str(cers_path), graph=flag)
+        t = TrainNNPrep(args, train_set=tr, val_set=SyntheticTextAreas(8, seed=2, include_name=True))
+        t.train()
+        if flag:
+            assert len(t.phase_a_graphs.graphs) >= 1 and len(t.phase_b_graphs.graphs) >= 1
+        res[flag] = [torch.cat([p.detach().flatten().clone() for p in m.parameters()]) for m in (t.crnn_model, t.prep_model)]
+    for a, b in zip(res[True], res[False]):
+        d = (a - b).abs().max().item()
+        assert d <= 5e-6, d
+
+
 def test_area_trainer_graph_replays_phase_b(tmp_path):
     """[new] --graph: Phase B of the area trainer as one hipGraph per shape (two eager steps, then capture, then replays) is the
     same training as the eager loop: same losses step by step, same weights after six steps."""

@@ -52,9 +52,45 @@ from bench.py's HIP events — the rocprofv3 trace of a run made of identical fu
 kernel {k0['mfma_busy']} MFMA-busy at a held {k0['clock_ghz']} GHz = {k0['mfma_busy'] * k0['clock_ghz'] / 2.4:.3f} of the peak (round 3: 0.647 at 1.81 = 0.488), no LDS bank conflicts (round 3's swizzle family: 0.135 per wave cycle); nine-tap wgrad (producer / consumer form) {k1['mfma_busy']} at {k1['clock_ghz']} GHz (round 3: 0.412 at 2.2); sum of kernel time in the
 single-stream trace {total / 13e6:.1f} ms per step.
 {END}'''
+    # single-stream time by class, from the same trace
+    cls = {"conv": 0.0, "wgrad": 0.0, "bn": 0.0, "lstm": 0.0, "pool": 0.0, "c1head": 0.0, "absmax": 0.0, "other": 0.0}
+    launches = 0
+    for row in csv.DictReader(open(P("profiles", "r04_kernel_stats_b2048_single_stream.csv"))):
+        n, t = pretty(row["Name"]), float(row["TotalDurationNs"]) / 13e6
+        launches += int(row["Calls"]) / 13
+        if ("wgrad" in n and "c1" not in n) or "splitk" in n or "bias_finalize" in n:
+            cls["wgrad"] += t
+        elif any(k in n for k in ("conv3x3", "conv_igemm", "gemm1x1")):
+            cls["conv"] += t
+        elif any(k in n for k in ("bn_", "colreduce", "partials", "colsum")):
+            cls["bn"] += t
+        elif "lstm" in n:
+            cls["lstm"] += t
+        elif "maxpool" in n:
+            cls["pool"] += t
+        elif any(k in n for k in ("c1_", "conv_c1", "head_")):
+            cls["c1head"] += t
+        elif "absmax" in n:
+            cls["absmax"] += t
+        else:
+            cls["other"] += t
+    tot = sum(cls.values())
+    hbm = cls["bn"] + cls["pool"] + cls["c1head"] + cls["absmax"]
+    classes = f"""<!-- classes:begin -->
+Single-stream time by class (`r04_kernel_stats_b2048_single_stream.csv`, {tot:.1f} ms of kernel time per step in {launches:.0f} launches; round 3:
+108.0 ms in 1 042): conv + GEMM {100 * cls['conv'] / tot:.0f} % ({cls['conv']:.1f} ms; round 3: 53.7, round 2: 83), wgrad incl. slab reductions {100 * cls['wgrad'] / tot:.0f} % ({cls['wgrad']:.1f}; 26.5; 36),
+BatchNorm (apply incl. the fused pools, backward incl. the fused pool backward, column sums) {100 * cls['bn'] / tot:.0f} % ({cls['bn']:.1f}; round 3: 14.2 + 3.1 of pool
+backward), the pool backward passes that are left {cls['pool']:.1f} ms, BiLSTM {100 * cls['lstm'] / tot:.1f} % ({cls['lstm']:.1f}), C_in = 1 convs + head {cls['c1head']:.1f} ms (incl. the CRNN's
+conv1 -> ReLU -> pool backward), abs-max passes {cls['absmax']:.1f}, everything else (CTC, Adam, jitter, decode / edit distance, derived weight forms,
+memsets) {cls['other']:.1f}.  The HBM-bound share is {hbm:.1f} ms = {100 * hbm / tot:.0f} % of the step (round 3: 20.3 ms = 19 %).  Box-to-box spread of one build is
+± 2.5 %, set by the clock the dominant kernel holds.
+<!-- classes:end -->"""
     s = open(P("DESIGN.md")).read()
     a, b = s.index(BEGIN), s.index(END) + len(END)
     s = s[:a] + nums + s[b:]
+    if "<!-- classes:begin -->" in s:
+        a, b = s.index("<!-- classes:begin -->"), s.index("<!-- classes:end -->") + len("<!-- classes:end -->")
+        s = s[:a] + classes + s[b:]
     open(P("DESIGN.md"), "w").write(s)
     s = open(P("profiles", "README.md")).read()
     s = re.sub(r"CROSSCHECK[^|]*\|", f"`{DOM}` {tr[0]} calls (13 steps × {tr[0] // 13}), average {tr[1]:.1f} µs in the trace against `roofline.avg_launch_us` = "
