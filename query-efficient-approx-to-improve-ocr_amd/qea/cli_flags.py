@@ -56,7 +56,7 @@ FLAGS = [
                                                       "The N documents go through the cleaner as ONE batch with per-document BatchNorm statistics "
                                                       "and through the CRNN of Phase B as one batch; forward values equal N sequential passes, the "
                                                       "gradients of the N documents accumulate into one Adam step"), "p"),
-    ("--graph", dict(action="store_true", help="[new] replay Phase B (cleaner -> CRNN -> CTC + MSE -> backward -> Adam) as ONE hipGraph per "
+    ("--graph", dict(action="store_true", help="[new] replay Phase B (cleaner -> CRNN -> CTC + MSE -> backward -> Adam) and the CRNN side of Phase A as ONE hipGraph each per "
                                                "(batch size, width): at the reference's batch sizes (tens of strips) a step is bound by the host "
                                                "time of ~600 launches, which the replay removes; the first two steps of a shape run eagerly, "
                                                "single-process runs only"), "a"),
