@@ -37,6 +37,9 @@ struct ConvArgs {
   const float* bst_shift;
 };
 
+// the 16x16x32 form of the LDS-halo conv lives in conv_halo16.hip
+int launch_halo_m16_any(int n_sel, int sm, const ConvArgs& a, hipStream_t s);
+
 // Shared epilogue of the MFMA conv kernels.  C/D map of a 32x32 accumulator tile: col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Order: v = acc*scale + bias; relu; mask; accumulate; store (out_mode remaps).
 // STATS: additionally accumulate, per output column, sum and sum of squares of the STORED values in fp64 (rows past M hold
