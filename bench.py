@@ -629,8 +629,8 @@ def main():
             out["full_step_select_before_clean"] = sel_first
         if c1 is not None:
             out["configs1_b512"] = c1
-        if world == 1 and not args.no_secondary and not args.phase_b_only and not args.graph and B >= 512:
-            out["small_batch"] = small_batch_legs()
+        if world == 1 and not use_dist and not args.no_secondary and not args.phase_b_only and not args.graph and B >= 512:
+            out["small_batch"] = small_batch_legs()          # (child processes of this bench: not under torch.distributed.run)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
