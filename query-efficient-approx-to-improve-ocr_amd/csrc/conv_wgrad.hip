@@ -1251,6 +1251,212 @@ __global__ __launch_bounds__(512) void wgrad_halo9_spec_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The producer / consumer form for 32-pixel-wide tiles with the X halo in a RING (round 4, tools/micro/wgrad_lab.hip: 380 -> 399 TFLOP/s at
+// 256 x 256 channels and 8 x 32 pixels, 297 -> 335 at 64 x 64 and 16 x 64, 397 -> 404 at 512 x 512 and 4 x 32).  A 2-row tile has a 4-row
+// halo: walking the tiles of one image column top to bottom, two of the four rows are the previous tile's.  A workgroup therefore takes
+// whole column strips (contiguous ranges of (image, column tile) pairs) and keeps the halo in a ring of 8 pixel rows: a tile reads ring
+// rows g .. g + 3, the producers meanwhile write the next tile's NEW rows — g + 4, g + 5 inside a strip, g + 4 .. g + 7 for the first tile
+// of the next strip — so they gather and split 68 instead of 136 halo pixels per tile.  g is even and a ring row holds an even number of
+// pixels, so the chunk-swap parity of a tap only needs the row's index inside the halo: a tap's address is one of 16 per-tile registers
+// (4 rows x the 4 table entries) + an immediate.  Everything else as wgrad_halo9_spec_kernel; the tile -> split assignment differs (strips,
+// not a stride), so the two agree to fp32 rounding and each is bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+constexpr int H9R_ROWS = 8, H9R_HWD = 34;
+constexpr size_t halo9_ring_lds() { return (size_t)2 * (2 * 64 * 64 * 2) + (size_t)2 * H9R_ROWS * H9R_HWD * 64 * 2; }
+
+__global__ __launch_bounds__(512) void wgrad_halo9_ring_kernel(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ ws, int B, int H,
+                                                               int W, int R, int C, int ldp, int ldq, Halo9Plan hp, const float* __restrict__ pmax,
+                                                               const float* __restrict__ qmax, double* __restrict__ bias_ws) {
+  constexpr int SW = 32, TH = 2, HWD = H9R_HWD;
+  constexpr int P_PLANE_B = 64 * 64 * 2, QR_PLANE_B = H9R_ROWS * HWD * 64 * 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const Pbase = reinterpret_cast<char*>(smem);                          // [2 buffers][h, l][64 px][64 ch]
+  char* const Qbase = Pbase + 2 * (2 * P_PLANE_B);                            // [h, l][8 ring rows][34][64 ch]
+  float sp, sq, inv_p, inv_q;
+  qea_f16_scale(pmax[0], sp, inv_p);
+  qea_f16_scale(qmax[0], sq, inv_q);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = qea_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int c_blk = bid % hp.c_blks;
+  bid /= hp.c_blks;
+  const int r_blk = bid % hp.r_blks;
+  const int split = bid / hp.r_blks;
+  const int r0 = r_blk * 64, c0 = c_blk * 64;
+  const int n_strips = B * hp.tiles_x;                                        // (hp.splits <= n_strips)
+  const int s0 = (int)((long long)n_strips * split / hp.splits), s1 = (int)((long long)n_strips * (split + 1) / hp.splits);
+  const int ntl = (s1 - s0) * hp.tiles_y;                                     // this workgroup's tiles, in (strip, tile row) order
+  auto ring_of = [&](int t) { return ((t + t / hp.tiles_y) * 2) & 7; };      // + 2 per tile inside a strip, + 4 across strips
+
+  if (wave >= 4) {
+    // ---------------------------------------------------------------- producers
+    const int pt = tid - 256;
+    constexpr int NP = 64 * 16 / 256, NQ = (4 * HWD * 16 + 255) / 256;        // 4, 9 (a whole four-row halo at a strip start)
+    f32x4 preg[NP], qreg[NQ];
+    int q_rows = 0, q_ring0 = 0;                                              // what qreg holds: halo rows and their first ring row
+    const bool do_bias = bias_ws != nullptr && c_blk == 0;
+    double bsum[4] = {0.0, 0.0, 0.0, 0.0};
+    auto fetch = [&](int t) {
+      const int st = s0 + t / hp.tiles_y, ty = t % hp.tiles_y;
+      const int b = st / hp.tiles_x, x0 = (st % hp.tiles_x) * SW, y0 = ty * TH;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int e = pt + 256 * i;
+        const int c4 = e % 16, pix = e / 16;
+        const int py = pix / SW, px = pix - py * SW;
+        preg[i] = *reinterpret_cast<const f32x4*>(p + ((size_t)(b * H + y0 + py) * W + x0 + px) * ldp + r0 + c4 * 4);
+      }
+      const int hy0 = ty == 0 ? 0 : 2;                                        // all four halo rows at a strip start, else the two new ones
+      q_rows = 4 - hy0;
+      q_ring0 = (ring_of(t) + hy0) & 7;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int e = pt + 256 * i;
+        const int c4 = e % 16, hq = e / 16;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (hq < q_rows * HWD) {
+          const int hy = hy0 + hq / HWD, hx = hq % HWD;
+          const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(q + ((size_t)(b * H + iy) * W + ix) * ldq + c0 + c4 * 4);
+        }
+        qreg[i] = v;
+      }
+    };
+    auto row_off = [](int pix, int c4) { return pix * 64 + ((((c4 >> 3) ^ (pix >> 1)) & 1) << 5) + (c4 & 7) * 4; };   // 16-bit elements
+    auto stage = [&](int pbuf) {
+      _Float16* Ps = reinterpret_cast<_Float16*>(Pbase + pbuf * (2 * P_PLANE_B));
+      _Float16* Qs = reinterpret_cast<_Float16*>(Qbase);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int e = pt + 256 * i;
+        const int o = row_off(e / 16, e % 16);
+        if (do_bias) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) bsum[k] += (double)preg[i][k];
+        }
+        f16x4 h, l;
+        qea_split2_f16(preg[i], sp, h, l);
+        *reinterpret_cast<f16x4*>(Ps + o) = h;
+        *reinterpret_cast<f16x4*>(Ps + P_PLANE_B / 2 + o) = l;
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int e = pt + 256 * i;
+        const int hq = e / 16;
+        if (hq < q_rows * HWD) {
+          const int rr = (q_ring0 + hq / HWD) & 7;
+          const int o = row_off(rr * HWD + hq % HWD, e % 16);
+          f16x4 h, l;
+          qea_split2_f16(qreg[i], sq, h, l);
+          *reinterpret_cast<f16x4*>(Qs + o) = h;
+          *reinterpret_cast<f16x4*>(Qs + QR_PLANE_B / 2 + o) = l;
+        }
+      }
+    };
+    if (ntl > 0) {
+      fetch(0);
+      stage(0);
+      if (ntl > 1) fetch(1);
+    }
+    __syncthreads();                                         // tile 0 staged
+    for (int t = 0; t < ntl; ++t) {
+      if (t + 1 < ntl) stage((t + 1) & 1);
+      if (t + 2 < ntl) fetch(t + 2);
+      __syncthreads();                                       // consumers done with tile t, tile t + 1 complete
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double v = bsum[k];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        bsum[k] = v;
+      }
+      if (lane < 16) {
+        double* dst = bias_ws + (size_t)(split * 4 + (wave - 4)) * R + r0 + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = bsum[k];
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumers
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int g16 = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
+  const int l_pix = (g16 >> 1) * 8 + tq;
+  const int l_ch = (g16 & 1) * 16 + tpp * 4;
+  const int p_off = l_pix * 128 + ((((wr ^ (l_pix >> 1)) & 1) << 5) + l_ch) * 2;
+  int TQ[2][2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int hs = (par ? (l_pix + 1) >> 1 : l_pix >> 1) + b;
+      TQ[par][b] = l_pix * 128 + ((((wc ^ hs) & 1) << 5) + l_ch) * 2;
+    }
+  __syncthreads();                                           // tile 0 staged
+  for (int t = 0; t < ntl; ++t) {
+    const char* Pb = Pbase + (t & 1) * (2 * P_PLANE_B) + p_off;
+    const int g = ring_of(t);
+    int QB[4][2][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rowoff = ((g + k) & 7) * (HWD * 128);
+#pragma unroll
+      for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) QB[k][par][bb] = TQ[par][bb] + rowoff;
+    }
+    auto read_p = [&](int ks, f16x8* af) {
+      af[0] = tr_pair128(Pb + ks * 16 * 128);
+      af[1] = tr_pair128(Pb + P_PLANE_B + ks * 16 * 128);
+    };
+    auto read_q = [&](int f, f16x8* bf) {                   // f = ks * 9 + tap
+      const int ks = f / 9, tap = f % 9;
+      const int py = (ks * 16) / SW, px0 = (ks * 16) % SW;
+      const int k = py + tap / 3, col = px0 + tap % 3;
+      const char* src = Qbase + QB[k][col & 1][((col >> 1) + k) & 1] + col * 128;
+      bf[0] = tr_pair128(src);
+      bf[1] = tr_pair128(src + QR_PLANE_B);
+    };
+    f16x8 af[2][2], bq[2][2];
+    read_p(0, af[0]);
+    read_q(0, bq[0]);
+#pragma unroll
+    for (int f = 0; f < 36; ++f) {
+      const int ks = f / 9, tap = f % 9;
+      const f16x8* a = af[ks & 1];
+      const f16x8* b = bq[f & 1];
+      if (f + 1 < 36) read_q(f + 1, bq[(f + 1) & 1]);
+      if (tap == 0 && ks + 1 < 4) read_p(ks + 1, af[(ks + 1) & 1]);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc[tap], 0, 0, 0);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc[tap], 0, 0, 0);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc[tap], 0, 0, 0);
+      if (f + 1 < 36) {
+        if (tap == 0 && ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = ws + (size_t)split * R * 9 * C;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = r0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      out[((size_t)rr * 9 + t) * C + c0 + wc * 32 + fr] = (acc[t][r] * inv_p) * inv_q;
+    }
+}
+
 Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
   Halo9Plan h = {false, 0, 0, 0, 0, 0, 0, 0, 0, 64, 64, 1, 0};
   if (d->KH != 3 || d->KW != 3 || d->pad_h != 1 || d->pad_w != 1 || d->stride_h != 1 || d->stride_w != 1 || d->PH != d->QH || d->PW != d->QW) return h;
@@ -1277,6 +1483,7 @@ Halo9Plan halo9_plan(const qea_wgrad_desc* d) {
   // one 8-wave workgroup per CU (100 KB)
   int splits = d->splits > 0 ? d->splits : (h.spec ? 256 : 512) / (h.r_blks * h.c_blks);
   if (splits > h.n_tiles / 8) splits = h.n_tiles / 8;
+  if (h.spec && h.sw == 32 && splits > d->B * h.tiles_x) splits = d->B * h.tiles_x;   // the ring form deals whole column strips
   if (splits < 1) splits = 1;
   h.splits = splits;
   h.ok = true;
@@ -1322,8 +1529,21 @@ int launch_halo9_spec(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s
   return QEA_OK;
 }
 
+int launch_halo9_ring(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s, double* bias_ws) {
+  constexpr size_t lds = halo9_ring_lds();
+  const long long grid = (long long)h.r_blks * h.c_blks * h.splits;
+  static int attr_rc = (int)hipFuncSetAttribute((const void*)wgrad_halo9_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_rc != (int)hipSuccess) {
+    qea_set_error("qea_conv_wgrad: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString((hipError_t)attr_rc));
+    return QEA_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(wgrad_halo9_ring_kernel, dim3((unsigned)grid), dim3(512), lds, s, d->p, d->q, (float*)d->workspace, d->B, d->PH, d->PW, d->R, d->C,
+                     d->ldp, d->ldq, h, d->p_absmax, d->q_absmax, bias_ws);
+  return QEA_OK;
+}
+
 int launch_halo9(const qea_wgrad_desc* d, const Halo9Plan& h, hipStream_t s, double* bias_ws = nullptr) {
-  if (h.spec) return h.sw == 32 ? launch_halo9_spec<32>(d, h, s, bias_ws) : launch_halo9_spec<16>(d, h, s, bias_ws);
+  if (h.spec) return h.sw == 32 ? launch_halo9_ring(d, h, s, bias_ws) : launch_halo9_spec<16>(d, h, s, bias_ws);
   if (h.sw == 32) return h.rb == 64 ? launch_halo9_any<32, 64, 64>(d, h, s) : launch_halo9_any<32, 32, 32>(d, h, s);
   return h.rb == 64 ? launch_halo9_any<16, 64, 64>(d, h, s) : launch_halo9_any<16, 32, 32>(d, h, s);
 }

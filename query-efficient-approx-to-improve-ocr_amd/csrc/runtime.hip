@@ -49,7 +49,7 @@ extern "C" int qea_set_mfma_mode(int mode) {
 }
 
 extern "C" const char* qea_last_error(void) { return g_err; }
-extern "C" int qea_version(void) { return 8; }
+extern "C" int qea_version(void) { return 9; }
 
 void qea_prof_begin(int klass, hipStream_t s) {
   ProfClass& pc = g_prof[klass];

@@ -559,14 +559,35 @@ def lstm_pack_whh_split(w_hh, planes_fwd, planes_bwd):
     _lib.check(_lib.lib().qea_lstm_pack_whh_split(_ptr(w_hh), _ptr(planes_fwd), _ptr(planes_bwd), _stream()), "qea_lstm_pack_whh_split")
 
 
+LSTM_SEQ = {"on": os.environ.get("QEA_LSTM", "seq") != "step"}
+
+
+def lstm_mode():
+    """"seq": one launch per layer pass, W_hh resident in LDS as fp16 planes (csrc/lstm_seq.hip; the default fp16-split mode);
+    "bf3": one launch per step, split-bf16 recurrent GEMMs (QEA_LSTM=step, or the split-bf16 MFMA mode); "f32": QEA_MFMA=f32."""
+    m = mfma_mode()
+    if m == "f32":
+        return "f32"
+    return "seq" if (m == "split_f16" and LSTM_SEQ["on"]) else "bf3"
+
+
 def lstm_packs(whf, whr):
-    """(fwd pack, bwd pack, split) of one layer's two W_hh for the CURRENT MFMA mode, cached with the weights: three-plane
-    bf16 fragments for the split-bf16 step kernels (default), fp32 fragments for QEA_MFMA=f32."""
-    split = mfma_mode() != "f32"
+    """(fwd pack, bwd pack, mode) of one layer's two W_hh for the CURRENT mode (lstm_mode), cached with the weights: fp16 planes +
+    the two abs-max values for the one-launch layer kernels, three-plane bf16 fragments for the split-bf16 step kernels, fp32
+    fragments for QEA_MFMA=f32.  A "seq" pack is the tuple (planes [2][bytes], w_absmax [2])."""
+    mode = lstm_mode()
     dev = whf.device
 
     def pack():
-        if split:
+        if mode == "seq":
+            nb = _lib.lib().qea_lstm_seq_pack_bytes()
+            pf_ = torch.empty(2, nb, dtype=torch.uint8, device=dev)
+            pb_ = torch.empty(2, nb, dtype=torch.uint8, device=dev)
+            am = torch.empty(2, device=dev)
+            for d_, wh in enumerate((whf, whr)):
+                _lib.check(_lib.lib().qea_lstm_seq_pack(_ptr(wh), _ptr(pf_[d_]), _ptr(pb_[d_]), _ptr(am[d_:]), _stream()), "qea_lstm_seq_pack")
+            return (pf_, am), (pb_, am)
+        if mode == "bf3":
             nb = _lib.lib().qea_lstm_pack_whh_split_bytes()
             pf_ = torch.empty(2, nb, dtype=torch.uint8, device=dev)
             pb_ = torch.empty(2, nb, dtype=torch.uint8, device=dev)
@@ -578,19 +599,34 @@ def lstm_packs(whf, whr):
             for d_, wh in enumerate((whf, whr)):
                 lstm_pack_whh(wh, pf_[d_], pb_[d_])
         return pf_, pb_
-    pf, pb = weight_cached(("whh_pack", split), whf, pack, also=(whr,))
-    return pf, pb, split
+    pf, pb = weight_cached(("whh_pack", mode), whf, pack, also=(whr,))
+    return pf, pb, mode
 
 
-def lstm_layer_fwd_any(gates, c, y, pack, split, T, B):
-    if split:
+def _lstm_seq_ws(B, dev):
+    return torch.empty(_lib.lib().qea_lstm_seq_workspace_bytes(B), dtype=torch.uint8, device=dev)
+
+
+def lstm_layer_fwd_any(gates, c, y, pack, mode, T, B):
+    """mode: "seq" / "bf3" / "f32" (True / False of the round-2 callers = "bf3" / "f32")"""
+    if os.environ.get("QEA_LSTM_TRACE"):
+        print("lstm fwd", mode, T, B, flush=True)
+    if mode == "seq":
+        planes, am = pack
+        ws = _lstm_seq_ws(B, gates.device)
+        _lib.check(_lib.lib().qea_lstm_seq_fwd(_ptr(gates), _ptr(c), _ptr(y), _ptr(planes), _ptr(am), T, B, _ptr(ws), _stream()), "qea_lstm_seq_fwd")
+    elif mode is True or mode == "bf3":
         _lib.check(_lib.lib().qea_lstm_layer_fwd_split(_ptr(gates), _ptr(c), _ptr(y), _ptr(pack), T, B, _stream()), "qea_lstm_layer_fwd_split")
     else:
         lstm_layer_fwd(gates, c, y, pack, T, B)
 
 
-def lstm_layer_bwd_any(gates, c, dy, pack, split, dc_scratch, T, B):
-    if split:
+def lstm_layer_bwd_any(gates, c, dy, pack, mode, dc_scratch, T, B):
+    if mode == "seq":
+        planes, am = pack
+        ws = _lstm_seq_ws(B, gates.device)
+        _lib.check(_lib.lib().qea_lstm_seq_bwd(_ptr(gates), _ptr(c), _ptr(dy), _ptr(planes), _ptr(am), T, B, _ptr(ws), _stream()), "qea_lstm_seq_bwd")
+    elif mode is True or mode == "bf3":
         _lib.check(_lib.lib().qea_lstm_layer_bwd_split(_ptr(gates), _ptr(c), _ptr(dy), _ptr(pack), _ptr(dc_scratch), T, B, _stream()),
                    "qea_lstm_layer_bwd_split")
     else:

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name, _, _ in protos:
         assert hasattr(L, name), name
-    assert L.qea_version() == 8
+    assert L.qea_version() == 9
     # argument validation happens before any launch: a null descriptor is an error, not a crash
     assert L.qea_conv_igemm(None, None) < 0
     assert b"null" in L.qea_last_error()

@@ -249,7 +249,8 @@ def test_head_fwd_bwd():
 
 # ----------------------------------------------------------------------------- LSTM
 @pytest.mark.parametrize("T,B,step", [(31, 5, "f32"), (7, 70, "f32"), (31, 5, "split"), (7, 70, "split"), (3, 1571, "split"), (4, 2048, "split"),
-                                      (3, 1571, "f32")])
+                                      (3, 1571, "f32"), (31, 5, "seq"), (7, 70, "seq"), (3, 1571, "seq"), (4, 2048, "seq"), (31, 512, "seq"),
+                                      (31, 600, "seq")])
 def test_lstm_layer_fwd_bwd(T, B, step):
     """step = "f32": lstm_step_kernel (v_mfma_f32_32x32x2_f32); "split": lstm_step_bf3_kernel (split-bf16 recurrent GEMMs; 32-row
     workgroups below 1 536 rows, 128-row workgroups with LDS-DMA weight stages above, ragged last row block included)."""
@@ -277,7 +278,19 @@ def test_lstm_layer_fwd_bwd(T, B, step):
         ops.conv_igemm(xd, P["w_ih" + s].detach().to(dev), gates[:, :, d * 1024:], B=1, H=1, W=T * B, Cin=In, OH=1, OW=T * B,
                        N=1024, KH=1, KW=1, ldx=In, ldy=2048, bias=bias)
     split = step == "split"
-    if split:
+    if step == "seq":
+        # one launch per pass: W_hh in LDS as fp16 planes, h / gate gradients exchanged inside the launch (csrc/lstm_seq.hip);
+        # 32-row workgroups up to 512 rows, 128-row ones above
+        from qea import _lib
+        assert _lib.lib().qea_lstm_seq_pack_bytes() == 1024 * 256 * 2 * 2
+        old = ops.LSTM_SEQ["on"]
+        ops.LSTM_SEQ["on"] = True
+        try:
+            pf, pb, split = ops.lstm_packs(P["w_hh"].detach().to(dev), P["w_hh_reverse"].detach().to(dev))
+        finally:
+            ops.LSTM_SEQ["on"] = old
+        assert split == "seq"
+    elif split:
         from qea import _lib
         nb = _lib.lib().qea_lstm_pack_whh_split_bytes()
         assert nb == 1024 * 256 * 3 * 2
@@ -285,7 +298,8 @@ def test_lstm_layer_fwd_bwd(T, B, step):
     else:
         pf, pb = torch.empty(2, 1024 * 256, device=dev), torch.empty(2, 1024 * 256, device=dev)
     for d, s in enumerate(("", "_reverse")):
-        (ops.lstm_pack_whh_split if split else ops.lstm_pack_whh)(P["w_hh" + s].detach().to(dev), pf[d], pb[d])
+        if step != "seq":
+            (ops.lstm_pack_whh_split if split else ops.lstm_pack_whh)(P["w_hh" + s].detach().to(dev), pf[d], pb[d])
     c, y = torch.empty(T, B, 512, device=dev), torch.empty(T, B, 512, device=dev)
     ops.lstm_layer_fwd_any(gates, c, y, pf, split, T, B)
     torch.cuda.synchronize()

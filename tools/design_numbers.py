@@ -8,7 +8,7 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda *a: os.path.join(ROOT, *a)
 DOM = "conv3x3_halo_m16_kernel<128, false, 0, 0, false>"
-WG = "wgrad_halo9_spec_kernel<32>"
+WG = "wgrad_halo9_ring_kernel"
 sys_path = os.path.join(ROOT, "tools")
 import sys
 sys.path.insert(0, sys_path)

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <type_traits>
 #include "qea_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -245,6 +246,199 @@ __global__ __launch_bounds__(512) void wgrad_spec_kernel(const float* __restrict
     }
 }
 
+// ---- RING variant: a workgroup walks whole column strips (all the 2-row tiles of one image column, top to bottom) and keeps the X halo
+// in a RING of 8 pixel rows: a tile's halo is ring rows g .. g + 3, the next tile of the strip needs rows g + 2 .. g + 5, i.e. only TWO new
+// rows (the first tile of the next strip: four, at g + 4 .. g + 7) — the producers gather and split 68 instead of 136 halo pixels per tile.
+constexpr int RING_ROWS = 8;
+constexpr int QR_PLANE_B = RING_ROWS * HWD * 64 * 2;                          // bytes per plane of the ring
+constexpr int RING_LDS = 2 * (2 * P_PLANE_B) + 2 * QR_PLANE_B;                // two P buffers (h, l each) + the ring (h, l)
+
+template <int VAR>
+__global__ __launch_bounds__(512) void wgrad_ring_kernel(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ ws, int B, int H, int W,
+                                                         int R, int C, int ldp, int ldq, Plan hp, const float* __restrict__ pmax,
+                                                         const float* __restrict__ qmax) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const Pbase = lds;                                                    // [2 buffers][h, l][64 px][64 ch]
+  char* const Qbase = lds + 2 * (2 * P_PLANE_B);                              // [h, l][8 ring rows][34][64 ch]
+  float sp, sq, inv_p, inv_q;
+  f16_scale(pmax[0], sp, inv_p);
+  f16_scale(qmax[0], sq, inv_q);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int c_blk = bid % hp.c_blks;
+  bid /= hp.c_blks;
+  const int r_blk = bid % hp.r_blks;
+  const int split = bid / hp.r_blks;
+  const int r0 = r_blk * 64, c0 = c_blk * 64;
+  // strips of this workgroup: a contiguous range of (image, column tile) pairs
+  const int n_strips = B * hp.tiles_x;
+  const int s0 = (int)((long long)n_strips * split / hp.splits), s1 = (int)((long long)n_strips * (split + 1) / hp.splits);
+  const int ntl = (s1 - s0) * hp.tiles_y;                                     // tiles, in (strip, ty) order
+  auto tile_of = [&](int t, int& b, int& x0, int& y0, bool& first) {
+    const int st = s0 + t / hp.tiles_y, ty = t % hp.tiles_y;
+    b = st / hp.tiles_x;
+    x0 = (st % hp.tiles_x) * SW;
+    y0 = ty * TH;
+    first = ty == 0;
+  };
+  // ring base (first halo row) of tile t: + 2 per tile inside a strip, + 4 across strips -> ((t + t / tiles_y) * 2) & 7
+  auto ring_of = [&](int t) { return ((t + t / hp.tiles_y) * 2) & 7; };
+
+  if (producer) {
+    const int pt = tid - 256;
+    constexpr int NP = 64 * 16 / 256, NQ = (4 * HWD * 16 + 255) / 256;        // 4, 9 (a whole four-row halo at a strip start)
+    f32x4 preg[NP], qreg[NQ];
+    int q_rows = 0, q_ring0 = 0;                                              // what qreg holds: rows of the halo and their first ring row
+    auto fetch = [&](int t) {
+      int b, x0, y0;
+      bool first;
+      tile_of(t, b, x0, y0, first);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int e = pt + 256 * i;
+        const int c4 = e % 16, pix = e / 16;
+        const int py = pix / SW, px = pix - py * SW;
+        preg[i] = *reinterpret_cast<const f32x4*>(p + ((size_t)(b * H + y0 + py) * W + x0 + px) * ldp + r0 + c4 * 4);
+      }
+      // halo rows to bring: all four (hy = 0 .. 3) for the first tile of a strip, else the two new ones (hy = 2, 3)
+      const int hy0 = first ? 0 : 2;
+      q_rows = 4 - hy0;
+      q_ring0 = (ring_of(t) + hy0) & 7;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int e = pt + 256 * i;
+        const int c4 = e % 16, hq = e / 16;                                   // pixel of the rows being fetched
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (hq < q_rows * HWD) {
+          const int hy = hy0 + hq / HWD, hx = hq % HWD;
+          const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const f32x4*>(q + ((size_t)(b * H + iy) * W + ix) * ldq + c0 + c4 * 4);
+        }
+        qreg[i] = v;
+      }
+    };
+    auto row_off = [](int pix, int c4) { return pix * 64 + ((((c4 >> 3) ^ (pix >> 1)) & 1) << 5) + (c4 & 7) * 4; };   // elements
+    auto stage = [&](int pbuf) {
+      _Float16* Ps = reinterpret_cast<_Float16*>(Pbase + pbuf * (2 * P_PLANE_B));
+      _Float16* Qs = reinterpret_cast<_Float16*>(Qbase);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int e = pt + 256 * i;
+        const int o = row_off(e / 16, e % 16);
+        f16x4 h, l;
+        split2_f16(preg[i], sp, h, l);
+        *reinterpret_cast<f16x4*>(Ps + o) = h;
+        *reinterpret_cast<f16x4*>(Ps + P_PLANE_B / 2 + o) = l;
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int e = pt + 256 * i;
+        const int hq = e / 16;
+        if (hq < q_rows * HWD) {
+          const int rr = (q_ring0 + hq / HWD) & 7;
+          const int o = row_off(rr * HWD + hq % HWD, e % 16);
+          f16x4 h, l;
+          split2_f16(qreg[i], sq, h, l);
+          *reinterpret_cast<f16x4*>(Qs + o) = h;
+          *reinterpret_cast<f16x4*>(Qs + QR_PLANE_B / 2 + o) = l;
+        }
+      }
+    };
+    if (ntl > 0) {
+      fetch(0);
+      stage(0);
+      if (ntl > 1) fetch(1);
+    }
+    __syncthreads();                                         // tile 0 staged
+    for (int t = 0; t < ntl; ++t) {
+      if (t + 1 < ntl) stage((t + 1) & 1);
+      if (t + 2 < ntl) fetch(t + 2);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------- consumers
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int g16 = lane >> 4, tq = (lane & 15) >> 2, tpp = lane & 3;
+  const int l_pix = (g16 >> 1) * 8 + tq;
+  const int l_ch = (g16 & 1) * 16 + tpp * 4;
+  const int p_off = l_pix * 128 + ((((wr ^ (l_pix >> 1)) & 1) << 5) + l_ch) * 2;
+  int TQ[2][2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int hs = (par ? (l_pix + 1) >> 1 : l_pix >> 1) + b;
+      TQ[par][b] = l_pix * 128 + ((((wc ^ hs) & 1) << 5) + l_ch) * 2;
+    }
+  __syncthreads();                                           // tile 0 staged
+  for (int t = 0; t < ntl; ++t) {
+    const char* Pb = Pbase + (t & 1) * (2 * P_PLANE_B) + p_off;
+    // the four halo rows of this tile sit at ring rows (g + k) & 7, g even: the chunk-swap parity of a tap's pixel offset only needs k & 1
+    // (a row holds an even number of pixels), so a tap's address is one of 16 per-tile registers + an immediate column offset
+    const int g = ring_of(t);
+    int QB[4][2][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rowoff = ((g + k) & 7) * (HWD * 128);
+#pragma unroll
+      for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) QB[k][par][bb] = TQ[par][bb] + rowoff;
+    }
+    {
+      auto read_p = [&](int ks, f16x8* af) {
+        af[0] = tr_pair(Pb + ks * 16 * 128);
+        af[1] = tr_pair(Pb + P_PLANE_B + ks * 16 * 128);
+      };
+      auto read_q = [&](int f, f16x8* bf) {                   // f = ks * 9 + tap
+        const int ks = f / 9, tap = f % 9;
+        const int py = (ks * 16) / SW, px0 = (ks * 16) % SW;
+        const int k = py + tap / 3, col = px0 + tap % 3;
+        const char* src = Qbase + QB[k][col & 1][((col >> 1) + k) & 1] + col * 128;
+        bf[0] = tr_pair(src);
+        bf[1] = tr_pair(src + QR_PLANE_B);
+      };
+      f16x8 af[2][2], bq[2][2];
+      read_p(0, af[0]);
+      read_q(0, bq[0]);
+#pragma unroll
+      for (int f = 0; f < 36; ++f) {
+        const int ks = f / 9, tap = f % 9;
+        const f16x8* a = af[ks & 1];
+        const f16x8* b = bq[f & 1];
+        if (f + 1 < 36) read_q(f + 1, bq[(f + 1) & 1]);
+        if (tap == 0 && ks + 1 < 4) read_p(ks + 1, af[(ks + 1) & 1]);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc[tap], 0, 0, 0);
+        if (f + 1 < 36) {
+          if (tap == 0 && ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = ws + (size_t)split * R * 9 * C;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = r0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      out[((size_t)rr * 9 + t) * C + c0 + wc * 32 + fr] = (acc[t][r] * inv_p) * inv_q;
+    }
+}
+
 __global__ void reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n, int splits) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float s = ws[i];
@@ -324,9 +518,18 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&stamps, (size_t)grid * 4 * 8));
   const size_t ldsb = 2 * BUF_B;
 
-  std::vector<Variant> vs = {VARIANT("spec", 0), VARIANT("spec prio", V_PRIO), VARIANT("spec abl no producer work", V_NOPROD), VARIANT("spec stamp", V_STAMP)};
-  for (auto& v : vs) CK(hipFuncSetAttribute((const void*)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+  std::vector<Variant> vs = {VARIANT("spec", 0), VARIANT("spec prio", V_PRIO), VARIANT("spec abl no producer work", V_NOPROD), VARIANT("spec stamp", V_STAMP),
+                             {"ring", 4096, nullptr}};
+  CK(hipFuncSetAttribute((const void*)wgrad_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RING_LDS));
+  for (auto& v : vs) if (v.kern) CK(hipFuncSetAttribute((const void*)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
   auto launch = [&](const Variant& v) {
+    if (v.var == 4096) {
+      Plan hr = hp;
+      if (hr.splits > B * hr.tiles_x) hr.splits = B * hr.tiles_x;
+      hipLaunchKernelGGL(wgrad_ring_kernel<0>, dim3(hr.r_blks * hr.c_blks * hr.splits), dim3(512), (size_t)RING_LDS, 0, p, q, ws, B, H, W, R, C, R, C, hr, pmax, qmax);
+      hipLaunchKernelGGL(reduce_kernel, dim3(std::min<long long>(2048, (nd + 255) / 256)), dim3(256), 0, 0, ws, dw, (long long)nd, hr.splits);
+      return;
+    }
     hipLaunchKernelGGL(v.kern, dim3(grid), dim3(512), ldsb, 0, p, q, ws, B, H, W, R, C, R, C, hp, pmax, qmax, stamps);
     hipLaunchKernelGGL(reduce_kernel, dim3(std::min<long long>(2048, (nd + 255) / 256)), dim3(256), 0, 0, ws, dw, (long long)nd, splits);
   };

@@ -18,7 +18,7 @@ from kname import pretty
 CLASSES = {
     "conv_igemm": (("conv_igemm_kernel", "conv_igemm_bf3_kernel", "conv_igemm_bf3w_kernel", "conv_igemm_p3_kernel", "conv3x3_halo_kernel",
                     "conv3x3_halo_bf3_kernel", "conv3x3_halo_m16_kernel", "gemm1x1_f16_kernel"), ()),
-    "conv_wgrad": (("wgrad_kernel", "wgrad_bf3_kernel", "wgrad_halo_kernel", "wgrad_halo9_bf3_kernel", "wgrad_halo9_spec_kernel"), ("splitk_reduce_kernel",)),
+    "conv_wgrad": (("wgrad_kernel", "wgrad_bf3_kernel", "wgrad_halo_kernel", "wgrad_halo9_bf3_kernel", "wgrad_halo9_spec_kernel", "wgrad_halo9_ring_kernel"), ("splitk_reduce_kernel",)),
 }
 
 
