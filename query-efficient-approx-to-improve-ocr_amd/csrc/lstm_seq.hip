@@ -103,6 +103,10 @@ __global__ void pack16_kernel(const float* __restrict__ src, _Float16* __restric
   *reinterpret_cast<f16x8*>(o + 512) = pl;
 }
 
+#ifndef SEQ_NBUF4
+#define SEQ_NBUF4 3
+#endif
+
 struct SeqArgs {
   float* gates;            // [T][B][2 * 1024]
   float* c;                // [T][B][2 * 256]
@@ -146,9 +150,10 @@ __device__ __forceinline__ void tile_frag(const float* T, int kk, float s, f16x8
     al[k] = l0[k]; al[k + 4] = l1[k];
   }
 }
-__device__ __forceinline__ void store_frag_sc1(const f16x8& ah, const f16x8& al, __amdgpu_buffer_rsrc_t dst, int off) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ah), dst, off, 0, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, al), dst, off + 1024, 0, 16);
+__device__ __forceinline__ void store_frag_sc1(const f16x8& ah, const f16x8& al, __amdgpu_buffer_rsrc_t dst, int soff) {   // soff: wave-uniform
+  const int voff = (threadIdx.x & 63) * 16;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ah), dst, voff, soff, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, al), dst, voff, soff + 1024, 16);
 }
 
 __device__ __forceinline__ void decode_block(int& group, int& u) {
@@ -283,12 +288,15 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const SeqArgs p) {
   // x * W_ih^T + b of a step is loaded one step ahead: behind the arrival of the step before, in front of that step's own stores of
   // y / activations / c, so that the reads and the writes of a step overlap in HBM
   float gx[NE][4];
+  int voffg[NE];                                        // byte offset of (row, direction, unit) inside one time step of gates (32-bit: one
+#pragma unroll                                          // register per element instead of a hoisted 64-bit address per element and array)
+  for (int i = 0; i < NE; ++i) voffg[i] = (min(erow[i], B - 1) * (2 * GATES) + d * GATES + unit) * 4;
   auto load_gx = [&](int t) {
-    const float* const g_t = p.gates + (size_t)t * B * (2 * GATES) + d * GATES + unit;
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates + (size_t)t * B * (2 * GATES), 0, B * (2 * GATES) * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NE; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) gx[i][j] = erow[i] < B ? g_t[(size_t)erow[i] * (2 * GATES) + j * HID] : 0.f;
+      for (int j = 0; j < 4; ++j) gx[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gsrc, voffg[i], j * HID * 4, 0));
   };
   load_gx(d ? T - 1 : 0);
 
@@ -308,8 +316,8 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const SeqArgs p) {
       u32x4 a[16][2];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        a[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ks * 2048 + lane * 16, 0, LDAUX);
-        a[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ks * 2048 + 1024 + lane * 16, 0, LDAUX);
+        a[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, lane * 16, ks * 2048, LDAUX);        // the k-step in the scalar offset
+        a[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, lane * 16, ks * 2048 + 1024, LDAUX);
       }
       __builtin_amdgcn_sched_barrier(0);               // all 32 fragment loads in flight before the first MFMA (left alone, hipcc sinks
                                                        // every load next to its use: one exposed round trip per fragment)
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const SeqArgs p) {
         for (int kk = 0; kk < 2; ++kk) {
           f16x8 ah, al;
           tile_frag(Te, kk, sh, ah, al);
-          store_frag_sc1(ah, al, xdst, (2 * u + kk) * 2048 + lane * 16);
+          store_frag_sc1(ah, al, xdst, (2 * u + kk) * 2048);
         }
         __builtin_amdgcn_wave_barrier();
       } else {
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const SeqArgs p) {
         if (w < 2) {
           f16x8 ah, al;
           tile_frag(Te, w, sh, ah, al);
-          store_frag_sc1(ah, al, xdst, (2 * u + w) * 2048 + lane * 16);
+          store_frag_sc1(ah, al, xdst, (2 * u + w) * 2048);
         }
       }
       publish(ctr);
@@ -395,7 +403,7 @@ template <int RG, bool ACQ>
 __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
   constexpr int NCH = RG == 4 ? 8 : 2;                // chunks (producers) per wave
   constexpr int NE = RG == 4 ? 16 : 4;
-  constexpr int NBUF = RG == 4 ? 3 : 2;               // chunk buffers (NBUF - 1 in flight ahead of the multiply)
+  constexpr int NBUF = RG == 4 ? SEQ_NBUF4 : 2;               // chunk buffers (NBUF - 1 in flight ahead of the multiply)
   constexpr int LDAUX = ACQ ? 0 : 16;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const Wl = lds;                                // [ks 64][plane 2][lane 64][16 B]
@@ -427,8 +435,13 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
     erow[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
   }
   float dcreg[NE];
+  int voffg[NE], voffc[NE];                             // byte offsets of (row, direction, unit) inside one time step of gates / of c, dy
 #pragma unroll
-  for (int i = 0; i < NE; ++i) dcreg[i] = 0.f;
+  for (int i = 0; i < NE; ++i) {
+    dcreg[i] = 0.f;
+    voffg[i] = (min(erow[i], B - 1) * (2 * GATES) + d * GATES + unit) * 4;
+    voffc[i] = (min(erow[i], B - 1) * (2 * HID) + d * HID + unit) * 4;
+  }
   const int ch0 = RG == 4 ? 0 : 2 * w;                 // this wave's first chunk
   bool failed = false;
   __syncthreads();
@@ -437,21 +450,20 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
     const int e = d ? k : T - 1 - k;
     const int et = d ? e + 1 : e - 1;                   // predecessor of e in time
     const bool has_prev = d ? (e < T - 1) : (e > 0);
-    const float* const g_e = p.gates + (size_t)e * B * (2 * GATES) + d * GATES + unit;
-    const float* const c_e = p.c + (size_t)e * B * (2 * HID) + d * HID + unit;
-    const float* const c_p = p.c + (size_t)et * B * (2 * HID) + d * HID + unit;
-    const float* const dy_e = p.dy + (size_t)e * B * (2 * HID) + d * HID + unit;
     float ga[NE][4], dyv[NE], cv[NE], cpv[NE];
     auto load_operands = [&]() {                        // the gate backward's inputs of step e: nobody's output in this launch
+      const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates + (size_t)e * B * (2 * GATES), 0, B * (2 * GATES) * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy) + (size_t)e * B * (2 * HID), 0, B * (2 * HID) * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t csrc = __builtin_amdgcn_make_buffer_rsrc(p.c + (size_t)e * B * (2 * HID), 0, B * (2 * HID) * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t psrc = __builtin_amdgcn_make_buffer_rsrc(p.c + (size_t)(has_prev ? et : e) * B * (2 * HID), 0, B * (2 * HID) * 4, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        const bool live = erow[i] < B;
-        const size_t ro = (size_t)(live ? erow[i] : 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ga[i][j] = g_e[ro * (2 * GATES) + j * HID];
-        dyv[i] = dy_e[ro * (2 * HID)];
-        cv[i] = c_e[ro * (2 * HID)];
-        cpv[i] = has_prev ? c_p[ro * (2 * HID)] : 0.f;
+        for (int j = 0; j < 4; ++j) ga[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gsrc, voffg[i], j * HID * 4, 0));
+        dyv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dsrc, voffc[i], 0, 0));
+        cv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(csrc, voffc[i], 0, 0));
+        const float cp = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(psrc, voffc[i], 0, 0));
+        cpv[i] = has_prev ? cp : 0.f;
       }
     };
 
@@ -471,10 +483,10 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
       auto load_chunk = [&](int ch, int b) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          a[b][q][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (ch * 8 + q) * 2048 + lane * 16, 0, LDAUX);
-          a[b][q][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (ch * 8 + q) * 2048 + 1024 + lane * 16, 0, LDAUX);
+          a[b][q][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, lane * 16, (ch * 8 + q) * 2048, LDAUX);
+          a[b][q][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, lane * 16, (ch * 8 + q) * 2048 + 1024, LDAUX);
         }
-        inv[b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xsrc, 64 * 2048 + ch * 128, 0, LDAUX));
+        inv[b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xsrc, 0, 64 * 2048 + ch * 128, LDAUX));
       };
       // NBUF - 1 chunks (16 KB per wave each) in flight ahead of the one being multiplied; the schedule is pinned (left alone, hipcc
       // sinks every load next to its use: one exposed round trip per fragment, 35 us per step)
@@ -556,7 +568,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
           for (int kk = 0; kk < 2; ++kk) {
             f16x8 ah, al;
             tile_frag(Te, kk, sa, ah, al);
-            store_frag_sc1(ah, al, xdst, (u * 8 + j * 2 + kk) * 2048 + lane * 16);
+            store_frag_sc1(ah, al, xdst, (u * 8 + j * 2 + kk) * 2048);
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
         for (int kk = 0; kk < 2; ++kk) {
           f16x8 ah, al;
           tile_frag(X + w * 1024, kk, sa, ah, al);
-          store_frag_sc1(ah, al, xdst, (u * 8 + w * 2 + kk) * 2048 + lane * 16);
+          store_frag_sc1(ah, al, xdst, (u * 8 + w * 2 + kk) * 2048);
         }
       }
       publish(ctr);
@@ -589,18 +601,20 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
 // exchanged rows through L1 behind an agent acquire (true) or by sc1 loads (false), per kernel shape
 constexpr bool SEQ_ACQ_FWD4 = false, SEQ_ACQ_FWD1 = false, SEQ_ACQ_BWD4 = false, SEQ_ACQ_BWD1 = false;
 
-inline int seq_row_groups(int B) { return B > 512 ? 4 : 1; }
-inline int seq_groups(int B) { return qea_cdiv(B, 32 * seq_row_groups(B)) * 2; }
-inline size_t seq_sync_words(int B) { return (size_t)((seq_groups(B) + 1 + 63) & ~63); }    // the exchange area starts on a 256-byte line
-inline int seq_nrb(int B) { return qea_cdiv(B, 32 * seq_row_groups(B)) * seq_row_groups(B); }
-inline size_t seq_xch_bytes(int B) { return (size_t)2 * 2 * seq_nrb(B) * XRB_BWD; }
+// 128-row workgroups once the 32-row ones would not all be resident at once; the backward's 128-row shape (512 KB of fragments per
+// workgroup and step) only pays above 1024 rows (B = 1024: 652 us against 2 x 278 for two rounds of 32-row workgroups)
+inline int seq_row_groups(int B, bool bwd) { return B > (bwd ? 1024 : 512) ? 4 : 1; }
+inline int seq_groups(int B, bool bwd) { return qea_cdiv(B, 32 * seq_row_groups(B, bwd)) * 2; }
+inline size_t seq_sync_words(int B, bool bwd) { return (size_t)((seq_groups(B, bwd) + 1 + 63) & ~63); }    // the exchange area starts on a 256-byte line
+inline int seq_nrb(int B, bool bwd) { return qea_cdiv(B, 32 * seq_row_groups(B, bwd)) * seq_row_groups(B, bwd); }
+inline size_t seq_xch_bytes(int B, bool bwd) { return (size_t)2 * 2 * seq_nrb(B, bwd) * (bwd ? XRB_BWD : XRB_FWD); }
 
-template <void (*KERN)(const SeqArgs)>
+template <void (*KERN)(const SeqArgs), bool BWD>
 int seq_launch(const char* what, SeqArgs& a, int B, void* ws, hipStream_t s, int lds) {
-  const int ng = seq_groups(B);
+  const int ng = seq_groups(B, BWD);
   a.sync = (unsigned*)ws;
-  a.xch = (char*)ws + seq_sync_words(B) * 4;
-  a.nrb = seq_nrb(B);
+  a.xch = (char*)ws + seq_sync_words(B, BWD) * 4;
+  a.nrb = seq_nrb(B, BWD);
   a.tmo_index = ng;
   static int attr_rc = (int)hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   int rc = attr_rc;
@@ -608,7 +622,7 @@ int seq_launch(const char* what, SeqArgs& a, int B, void* ws, hipStream_t s, int
     qea_set_error("%s: cannot reserve %d bytes of LDS: %s", what, lds, hipGetErrorString((hipError_t)rc));
     return QEA_ERR_LAUNCH;
   }
-  rc = (int)hipMemsetAsync(ws, 0, seq_sync_words(B) * 4, s);
+  rc = (int)hipMemsetAsync(ws, 0, seq_sync_words(B, BWD) * 4, s);
   if (rc != (int)hipSuccess) {
     qea_set_error("%s: hipMemsetAsync: %s", what, hipGetErrorString((hipError_t)rc));
     return QEA_ERR_LAUNCH;
@@ -622,7 +636,11 @@ int seq_launch(const char* what, SeqArgs& a, int B, void* ws, hipStream_t s, int
 
 extern "C" size_t qea_lstm_seq_pack_bytes(void) { return (size_t)W_PLANES_HALFS * 2; }
 
-extern "C" size_t qea_lstm_seq_workspace_bytes(int32_t B) { return B > 0 ? seq_sync_words(B) * 4 + seq_xch_bytes(B) : 0; }
+extern "C" size_t qea_lstm_seq_workspace_bytes(int32_t B) {   // enough for either pass
+  if (B <= 0) return 0;
+  const size_t f = seq_sync_words(B, false) * 4 + seq_xch_bytes(B, false), b = seq_sync_words(B, true) * 4 + seq_xch_bytes(B, true);
+  return f > b ? f : b;
+}
 
 extern "C" int qea_lstm_seq_pack(const float* w_hh, void* planes_fwd, void* planes_bwd, float* w_absmax, void* stream) {
   QEA_REQUIRE(w_hh && w_absmax && (planes_fwd || planes_bwd), "qea_lstm_seq_pack: null pointer");
@@ -649,8 +667,8 @@ extern "C" int qea_lstm_seq_fwd(float* gates, float* c, float* y, const void* pl
   hipStream_t s = (hipStream_t)stream;
   qea_prof_begin(QEA_PROF_LSTM_STEP, s);
   int rc;
-  if (seq_row_groups(B) == 4) rc = seq_launch<lstm_seq_fwd_kernel<4, SEQ_ACQ_FWD4>>("qea_lstm_seq_fwd", a, B, workspace, s, W_SLICE_BYTES + 16384);
-  else rc = seq_launch<lstm_seq_fwd_kernel<1, SEQ_ACQ_FWD1>>("qea_lstm_seq_fwd", a, B, workspace, s, W_SLICE_BYTES + 16384 + 4096 + 4096);
+  if (seq_row_groups(B, false) == 4) rc = seq_launch<lstm_seq_fwd_kernel<4, SEQ_ACQ_FWD4>, false>("qea_lstm_seq_fwd", a, B, workspace, s, W_SLICE_BYTES + 16384);
+  else rc = seq_launch<lstm_seq_fwd_kernel<1, SEQ_ACQ_FWD1>, false>("qea_lstm_seq_fwd", a, B, workspace, s, W_SLICE_BYTES + 16384 + 4096 + 4096);
   qea_prof_end(QEA_PROF_LSTM_STEP, s, 2.0 * 2 * B * (double)GATES * HID * (T - 1), 0.0, 1);
   return rc;
 }
@@ -668,8 +686,8 @@ extern "C" int qea_lstm_seq_bwd(float* gates, const float* c, const float* dy, c
   hipStream_t s = (hipStream_t)stream;
   qea_prof_begin(QEA_PROF_LSTM_STEP, s);
   int rc;
-  if (seq_row_groups(B) == 4) rc = seq_launch<lstm_seq_bwd_kernel<4, SEQ_ACQ_BWD4>>("qea_lstm_seq_bwd", a, B, workspace, s, W_SLICE_BYTES + 16384 + 512);
-  else rc = seq_launch<lstm_seq_bwd_kernel<1, SEQ_ACQ_BWD1>>("qea_lstm_seq_bwd", a, B, workspace, s, W_SLICE_BYTES + 16384 + 4096 + 4096 + 128);
+  if (seq_row_groups(B, true) == 4) rc = seq_launch<lstm_seq_bwd_kernel<4, SEQ_ACQ_BWD4>, true>("qea_lstm_seq_bwd", a, B, workspace, s, W_SLICE_BYTES + 16384 + 512);
+  else rc = seq_launch<lstm_seq_bwd_kernel<1, SEQ_ACQ_BWD1>, true>("qea_lstm_seq_bwd", a, B, workspace, s, W_SLICE_BYTES + 16384 + 4096 + 4096 + 128);
   qea_prof_end(QEA_PROF_LSTM_STEP, s, 2.0 * 2 * B * (double)GATES * HID * (T - 1), 0.0, 1);
   return rc;
 }

@@ -257,7 +257,7 @@ class CRNNEngine:
         for layer in (1, 0):
             s = ctx["lstm"][layer]
             gates, cst, yl, xin = s["gates"], s["c"], s["y"], s["x"]
-            dc = torch.empty(B, 2 * HID, device=dev)
+            dc = None if s["split"] == "seq" else torch.empty(B, 2 * HID, device=dev)    # the one-launch kernels keep dc in registers
             ops.lstm_layer_bwd_any(gates, cst, dy, s["pb"], s["split"], dc, T, B)          # gates now hold dgates
             # ONE abs-max pass over the gate gradients serves the four weight-gradient GEMMs and the input-gradient GEMM of the layer
             # (a bound over both directions and all steps scales every slice of the tensor)

@@ -248,6 +248,48 @@ def test_head_fwd_bwd():
 
 
 # ----------------------------------------------------------------------------- LSTM
+@pytest.mark.parametrize("B", [70, 600, 1300])
+def test_lstm_seq_is_bit_identical_under_concurrent_load(B):
+    """The in-launch hand-off of csrc/lstm_seq.hip (write-through fragment stores, one arrival counter per (row block, direction),
+    sc1 loads) under UNEVEN load: a side stream keeps the chip busy with large GEMMs while the layer runs, so workgroups of a group
+    start at different times and some wait for a CU.  The kernels are deterministic: every run must equal the idle run bit for bit
+    (B = 70: groups spread over the XCDs; 600: 128-row forward, 32-row backward; 1300: 128-row both, ragged last row block)."""
+    from qea import ops
+    dev, T = "cuda", 31
+    g = torch.Generator().manual_seed(B)
+    wf, wr = (torch.randn(1024, 256, generator=g) / 16).to(dev), (torch.randn(1024, 256, generator=g) / 16).to(dev)
+    old = ops.LSTM_SEQ["on"]
+    ops.LSTM_SEQ["on"] = True
+    try:
+        pf, pb, mode = ops.lstm_packs(wf, wr)
+    finally:
+        ops.LSTM_SEQ["on"] = old
+    assert mode == "seq"
+    gx = (torch.randn(T, B, 2048, generator=g) * 0.5).to(dev)
+    dy = torch.randn(T, B, 512, generator=g).to(dev)
+
+    def layer():
+        gates, c, y = gx.clone(), torch.empty(T, B, 512, device=dev), torch.empty(T, B, 512, device=dev)
+        ops.lstm_layer_fwd_any(gates, c, y, pf, mode, T, B)
+        acts = gates.clone()
+        ops.lstm_layer_bwd_any(gates, c, dy, pb, mode, None, T, B)
+        return y, acts, c, gates
+
+    ref = layer()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).all() for t in ref)
+    a = torch.randn(4096, 4096, device=dev)
+    side = torch.cuda.Stream()
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(6 + 3 * rep):
+                a @ a
+        out = layer()
+        torch.cuda.synchronize()
+        for r, o in zip(ref, out):
+            assert torch.equal(r, o), rep
+
+
 @pytest.mark.parametrize("T,B,step", [(31, 5, "f32"), (7, 70, "f32"), (31, 5, "split"), (7, 70, "split"), (3, 1571, "split"), (4, 2048, "split"),
                                       (3, 1571, "f32"), (31, 5, "seq"), (7, 70, "seq"), (3, 1571, "seq"), (4, 2048, "seq"), (31, 512, "seq"),
                                       (31, 600, "seq")])
