@@ -410,6 +410,18 @@ int qea_lstm_seq_fwd(float* gates, float* c, float* y, const void* planes_fwd, c
 int qea_lstm_seq_bwd(float* gates, const float* c, const float* dy, const void* planes_bwd, const float* w_absmax, int32_t T,
                      int32_t B, void* workspace, void* stream);
 
+/* ABI v9 (additive).  Several derived weight forms in ONE launch (a model has ~110 of them per optimiser step, a few microseconds each):
+ * kind 0 = qea_filter_flip_transpose (a, b, c, d = Co, Ci, KH, KW; amax unused), kind 1 = qea_pack_frag_planes_f16 (a, b = N, Cin),
+ * kind 2 = qea_pack_frag_planes_f16_1x1 (a, b = N, K); same bytes as the single calls.  `jobs` is a HOST array of 1..64 jobs; a job
+ * must not read what another job of the same call writes (flip first, then pack the flipped filters in a second call). */
+typedef struct qea_wform_job {
+  const float* src;
+  void* dst;
+  const float* amax;
+  int32_t kind, a, b, c, d;
+} qea_wform_job;
+int qea_weight_forms_multi(const qea_wform_job* jobs, int32_t n, void* stream);
+
 /* log_softmax over the last dim (fn.log_softmax(.., 2), model_crnn.py:20) and its backward
  * dx = g - exp(lp)*sum(g), with the reference's NaN scrub (CRNN.backward_hook,
  * model_crnn.py:30-32, registered at train_nn_patch.py:94) when nan_scrub != 0; columns

@@ -56,6 +56,12 @@ _SCALARS = {
 _PROTO = re.compile(r"^(int|size_t|const char\*)\s+(qea_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
 
 
+class WformJob(C.Structure):
+    """qea_wform_job of include/qea_hip.h (qea_weight_forms_multi)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("amax", C.c_void_p), ("kind", C.c_int32), ("a", C.c_int32), ("b", C.c_int32),
+                ("c", C.c_int32), ("d", C.c_int32)]
+
+
 def header_prototypes(path=HEADER_PATH):
     """[(name, restype, [argtypes])] for every function the header declares."""
     text = open(path).read()

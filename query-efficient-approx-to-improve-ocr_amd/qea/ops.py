@@ -72,7 +72,7 @@ def bump_weight_epoch():
     _wepoch[0] += 1
 
 
-def weight_cached(kind, w, build, also=(), extra=None):
+def weight_cached(kind, w, build, also=(), extra=None, batch=None):
     """build() -> tensor(s) derived from the weight tensor `w` (and the tensors in `also`) only; cached per (kind, the
     tensor OBJECT) until one of them changes.  Entries die with the tensor object (weakref), so a new tensor that happens
     to reuse the address of a freed one can never hit.  `extra`: any further hashable the value depends on."""
@@ -91,9 +91,80 @@ def weight_cached(kind, w, build, also=(), extra=None):
     hit = _wcache.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is w:
         return hit[1]
+    if batch is not None and BATCH_FORMS["on"] and extra is None and w.is_cuda and (w.data_ptr() & 15) == 0:
+        return _batched_forms(key, w, also, batch, token)
     val = build()
     _wcache[key] = (ver, val, weakref.ref(w, lambda _r, key=key: _wcache.pop(key, None)))
     return val
+
+
+# ---- derived forms of one model in ONE launch (round 4).  A form that qea_weight_forms_multi can make registers a FormJob under its
+# cache key; the first miss after a weight update then builds every stale registered form of the SAME group whose weight lives in the
+# same flat parameter buffer (= the same model) with one launch, and the later requests of the step hit the cache.  Groups: "flip"
+# (flip-transposed filters) and "pack" (fragment planes; a pack of a flipped filter asks for the flipped filter first, which runs
+# the flip group).  Forms outside a flat buffer (tests, ad-hoc weights) keep their single launches.
+BATCH_FORMS = {"on": os.environ.get("QEA_BATCH_FORMS", "1") != "0"}
+_form_jobs = {}
+
+
+class FormJob:
+    """plain data (no reference to the weight: a registered job must not keep its tensor alive).  srck: "self" = the weight itself,
+    "flipT" = its flip-transposed form (dims of the 3x3 pack: N, Cin of the input-gradient conv); out: shape or byte count;
+    amax: (ld, M, Cc) of the filter_absmax call, or None."""
+    __slots__ = ("group", "kind", "dims", "srck", "out", "amax", "wref", "also")
+
+    def __init__(self, group, kind, dims, srck, out, amax):
+        self.group, self.kind, self.dims, self.srck, self.out, self.amax = group, kind, dims, srck, out, amax
+
+    def source(self, w):
+        return w if self.srck == "self" else flip_transposed(w, self.dims[1], self.dims[0], 3, 3)
+
+    def alloc(self, w):
+        return torch.empty(self.out, device=w.device) if isinstance(self.out, tuple) else torch.empty(self.out, dtype=torch.uint8, device=w.device)
+
+    def scale(self, w):
+        return None if self.amax is None else filter_absmax((self.srck, w), w, *self.amax)
+
+
+def _cache_ver(w, also, token, extra=None):
+    return (w.data_ptr(), w._version, _wepoch[0], _stream(), token, extra) + tuple((id(t), t.data_ptr(), t._version) for t in also)
+
+
+def _batched_forms(key, w, also, job, token):
+    """builds `key` and every other stale registered form of its group and model; returns key's tensor"""
+    from .params import flat_state_of
+    job.wref, job.also = weakref.ref(w), tuple(weakref.ref(t) for t in also)
+    _form_jobs[key] = job
+    fs = flat_state_of(w, check=False)
+    todo = [(key, w, also, job)]
+    if fs is not None:
+        dead = []                                            # jobs of weights that are gone: dropped here, never from a finalizer
+        for k2, j2 in _form_jobs.items():                    # (a callback that edits the dict could run inside this very loop)
+            w2 = j2.wref()
+            also2 = tuple(r() for r in j2.also)
+            if w2 is None or any(t is None for t in also2):
+                dead.append(k2)
+                continue
+            if k2 == key or j2.group != job.group or len(todo) >= 64 or flat_state_of(w2, check=False) is not fs:
+                continue
+            hit = _wcache.get(k2)
+            if hit is not None and hit[0] == _cache_ver(w2, also2, token) and hit[2]() is w2:
+                continue
+            todo.append((k2, w2, also2, j2))
+        for k2 in dead:
+            del _form_jobs[k2]
+    jobs = (_lib.WformJob * len(todo))()
+    outs, keep = [], []
+    for i, (_k, wi, _a, ji) in enumerate(todo):
+        src, out, am = ji.source(wi), ji.alloc(wi), ji.scale(wi)
+        keep.append((src, am))
+        outs.append(out)
+        jobs[i].src, jobs[i].dst, jobs[i].amax, jobs[i].kind = src.data_ptr(), out.data_ptr(), (am.data_ptr() if am is not None else None), ji.kind
+        jobs[i].a, jobs[i].b, jobs[i].c, jobs[i].d = ji.dims
+    _lib.check(_lib.lib().qea_weight_forms_multi(jobs, len(todo), _stream()), "qea_weight_forms_multi")
+    for (ki, wi, ai, _j), out in zip(todo, outs):
+        _wcache[ki] = (_cache_ver(wi, ai, token), out, weakref.ref(wi, lambda _r, key=ki: _wcache.pop(key, None)))
+    return outs[0]
 
 
 def flip_transposed(w, Co, Ci, KH, KW):
@@ -102,7 +173,7 @@ def flip_transposed(w, Co, Ci, KH, KW):
         wt = torch.empty(Ci, KH, KW, Co, device=w.device)
         filter_flip_transpose(w, wt, Co, Ci, KH, KW)
         return wt
-    return weight_cached(("flipT", Co, Ci, KH, KW), w, build)
+    return weight_cached(("flipT", Co, Ci, KH, KW), w, build, batch=FormJob("flip", 0, (Co, Ci, KH, KW), "self", (Ci, KH, KW, Co), None))
 
 
 def transposed(w, R, Cc):
@@ -145,7 +216,10 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
             wmax = filter_absmax(w_src, w, Cin, N, Cin)
             _lib.check(L.qea_pack_frag_planes_f16_1x1(_ptr(w), N, Cin, _ptr(wmax), out.data_ptr(), _stream()), "qea_pack_frag_planes_f16_1x1")
             return out
-        frag = weight_cached(("frag1x1", w_src[0], N, Cin), w_src[1], build, also=tuple(w_src[2]) if len(w_src) > 2 else ()) if w_src is not None else build()
+        job = None
+        if w_src is not None and w_src[0] == "fwd" and len(w_src) == 2 and w_src[1].data_ptr() == w.data_ptr():
+            job = FormJob("pack", 2, (N, Cin, 0, 0), "self", L.qea_pack_frag_planes_f16_1x1_bytes(N, Cin), (Cin, N, Cin))
+        frag = weight_cached(("frag1x1", w_src[0], N, Cin), w_src[1], build, also=tuple(w_src[2]) if len(w_src) > 2 else (), batch=job) if w_src is not None else build()
         d.w_frag_planes = frag.data_ptr()
         xmax = x_amax if x_amax is not None else absmax(x, ldx, B * H * W, Cin)
         d.x_absmax = xmax.data_ptr()
@@ -162,7 +236,16 @@ def conv_igemm(x, w, y, *, B, H, W, Cin, OH, OW, N, KH, KW, pad=(0, 0), stride=(
             out = torch.empty(L.qea_pack_frag_planes_bytes(N, Cin), dtype=torch.uint8, device=x.device)
             _lib.check(L.qea_pack_frag_planes(_ptr(w), N, Cin, out.data_ptr(), _stream()), "qea_pack_frag_planes")
             return out
-        frag = weight_cached(("fragf16" if f16 else "frag", w_src[0], N, Cin), w_src[1], build, also=tuple(w_src[2]) if len(w_src) > 2 else ()) if w_src is not None else build()
+        job = None
+        if f16 and w_src is not None and len(w_src) == 2 and KH == 3 and KW == 3:
+            nb = L.qea_pack_frag_planes_f16_bytes(N, Cin)
+            if w_src[0] == "fwd" and w_src[1].data_ptr() == w.data_ptr():
+                job = FormJob("pack", 1, (N, Cin, 0, 0), "self", nb, (9 * Cin, N, 9 * Cin))
+            elif w_src[0] == "flipT":
+                # the input-gradient filter: planes of the flip-transposed weight (itself a cached form: asked for first, which
+                # builds all stale flipped filters of the model in one launch)
+                job = FormJob("pack", 1, (N, Cin, 0, 0), "flipT", nb, (9 * N, Cin, 9 * N))
+        frag = weight_cached(("fragf16" if f16 else "frag", w_src[0], N, Cin), w_src[1], build, also=tuple(w_src[2]) if len(w_src) > 2 else (), batch=job) if w_src is not None else build()
         d.w_frag_planes = frag.data_ptr()
         if f16:
             # the input's abs-max: carried by the tensor's producer (x_amax), else one pass over the input here

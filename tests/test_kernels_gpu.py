@@ -247,6 +247,69 @@ def test_head_fwd_bwd():
     assert rel_err(dw.cpu(), w.grad.reshape(Cc)) < 1e-5 and rel_err(db.cpu(), b.grad) < 1e-5
 
 
+# ----------------------------------------------------------------------------- derived weight forms, several per launch
+def test_weight_forms_multi_equals_the_single_launches():
+    """qea_weight_forms_multi (csrc/weight_forms.hip): flip-transposed filters, 3x3 fragment planes (both chunk orders) and 1x1
+    fragment planes of several layers in ONE launch each group — the same bytes as the single calls."""
+    import ctypes as C
+    from qea import _lib, ops
+    L = _lib.lib()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    shapes3 = [(64, 32), (32, 32), (128, 64), (256, 128), (512, 512), (64, 64)]          # (Co, Ci) of 3x3 layers
+    ws = [(torch.randn(co, 3, 3, ci, generator=g) * (0.1 + i)).to(dev) for i, (co, ci) in enumerate(shapes3)]
+    # flips
+    single = []
+    for w, (co, ci) in zip(ws, shapes3):
+        wt = torch.empty(ci, 3, 3, co, device=dev)
+        ops.filter_flip_transpose(w, wt, co, ci, 3, 3)
+        single.append(wt)
+    jobs = (_lib.WformJob * len(ws))()
+    multi = [torch.empty_like(t) for t in single]
+    for i, (w, (co, ci)) in enumerate(zip(ws, shapes3)):
+        jobs[i].src, jobs[i].dst, jobs[i].amax, jobs[i].kind = w.data_ptr(), multi[i].data_ptr(), None, 0
+        jobs[i].a, jobs[i].b, jobs[i].c, jobs[i].d = co, ci, 3, 3
+    _lib.check(L.qea_weight_forms_multi(jobs, len(ws), st), "multi")
+    for a, b in zip(single, multi):
+        assert torch.equal(a, b)
+    # 3x3 planes of the forward filters (N = Co, Cin = Ci) and of the flipped ones (N = Ci, Cin = Co)
+    srcs = [(w, co, ci) for w, (co, ci) in zip(ws, shapes3)] + [(wt, ci, co) for wt, (co, ci) in zip(single, shapes3) if co >= 32 and ci >= 32]
+    srcs = [(w, n, c) for (w, n, c) in srcs if n in (32, 64) or n % 128 == 0]
+    amax = [ops.absmax(w, w.numel(), 1, w.numel()) for w, _, _ in srcs]
+    single = []
+    for (w, n, c), am in zip(srcs, amax):
+        out = torch.zeros(L.qea_pack_frag_planes_f16_bytes(n, c), dtype=torch.uint8, device=dev)
+        _lib.check(L.qea_pack_frag_planes_f16(w.data_ptr(), n, c, am.data_ptr(), out.data_ptr(), st), "single")
+        single.append(out)
+    jobs = (_lib.WformJob * len(srcs))()
+    multi = [torch.zeros_like(t) for t in single]
+    for i, ((w, n, c), am) in enumerate(zip(srcs, amax)):
+        jobs[i].src, jobs[i].dst, jobs[i].amax, jobs[i].kind = w.data_ptr(), multi[i].data_ptr(), am.data_ptr(), 1
+        jobs[i].a, jobs[i].b, jobs[i].c, jobs[i].d = n, c, 0, 0
+    _lib.check(L.qea_weight_forms_multi(jobs, len(srcs), st), "multi")
+    for a, b in zip(single, multi):
+        assert torch.equal(a, b)
+    # 1x1 planes
+    shapes1 = [(1024, 512), (128, 64), (512, 2048)]
+    w1 = [(torch.randn(n, k, generator=g) / k ** 0.5).to(dev) for n, k in shapes1]
+    amax = [ops.absmax(w, w.numel(), 1, w.numel()) for w in w1]
+    jobs = (_lib.WformJob * len(w1))()
+    single, multi = [], []
+    for i, (w, (n, k), am) in enumerate(zip(w1, shapes1, amax)):
+        out = torch.zeros(L.qea_pack_frag_planes_f16_1x1_bytes(n, k), dtype=torch.uint8, device=dev)
+        _lib.check(L.qea_pack_frag_planes_f16_1x1(w.data_ptr(), n, k, am.data_ptr(), out.data_ptr(), st), "single")
+        single.append(out)
+        multi.append(torch.zeros_like(out))
+        jobs[i].src, jobs[i].dst, jobs[i].amax, jobs[i].kind = w.data_ptr(), multi[i].data_ptr(), am.data_ptr(), 2
+        jobs[i].a, jobs[i].b, jobs[i].c, jobs[i].d = n, k, 0, 0
+    _lib.check(L.qea_weight_forms_multi(jobs, len(w1), st), "multi")
+    torch.cuda.synchronize()
+    for a, b in zip(single, multi):
+        assert torch.equal(a, b)
+    assert L.qea_weight_forms_multi(jobs, 65, st) < 0          # more than 64 jobs: refused, not truncated
+
+
 # ----------------------------------------------------------------------------- LSTM
 @pytest.mark.parametrize("B", [70, 600, 1300])
 def test_lstm_seq_is_bit_identical_under_concurrent_load(B):

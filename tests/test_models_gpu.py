@@ -839,3 +839,64 @@ def test_weights_loaded_after_a_forward_get_a_fresh_filter_scale():
         p.copy_(p * 16)
         y2 = net(x)
     assert torch.isfinite(y2).all()
+
+
+def test_batched_weight_forms_give_the_same_step():
+    """ops.BATCH_FORMS (round 4): all stale derived forms of a model (flipped filters, fragment planes) in one launch per group on the
+    first miss after a weight update.  Two optimiser steps of the UNet -> CRNN -> CTC chain with and without it: identical losses
+    and gradients bit for bit, a handful of multi-form launches instead of one launch per form, and a weight written through torch
+    between the steps is seen."""
+    from models.model_crnn import CRNN
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea import ops
+    from qea.loss import CTCLoss
+    labels = ["abc", "hello", "MI355X", "q"]
+    y, ysz = H.encode(labels)
+    x = torch.rand(4, 1, 32, 128, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run(on):
+        old = ops.BATCH_FORMS["on"]
+        ops.BATCH_FORMS["on"] = on
+        calls = []
+        orig = ops._batched_forms
+
+        def counting(key, w, also, job, token):
+            out = orig(key, w, also, job, token)
+            calls.append(key[0])
+            return out
+        ops._batched_forms = counting
+        try:
+            unet = _load(UNet(), mo.unet_state_shapes, 1).train()
+            crnn = _load(CRNN(95, False), mo.crnn_state_shapes, 2).train()
+            opt = torch.optim.SGD(list(unet.parameters()) + list(crnn.parameters()), lr=1e-3)
+            res = []
+            for it in range(2):
+                calls.append("step")
+                opt.zero_grad(set_to_none=True)
+                lp = crnn(unet(x))
+                T = lp.shape[0]
+                loss = CTCLoss()(lp, y, torch.full((4,), T, dtype=torch.int), ysz)
+                loss.backward()
+                res.append([loss.detach().clone()] + [p.grad.detach().clone() for p in list(unet.parameters()) + list(crnn.parameters())])
+                opt.step()
+                if it == 0:
+                    with torch.no_grad():
+                        next(q for q in unet.parameters() if q.dim() == 4 and q.shape[1] > 1).mul_(1.5)      # a write through torch
+            torch.cuda.synchronize()
+            return res, calls
+        finally:
+            ops._batched_forms = orig
+            ops.BATCH_FORMS["on"] = old
+
+    a, calls_on = run(True)
+    b, calls_off = run(False)
+    assert [c for c in calls_off if c != "step"] == []
+    for ra, rb in zip(a, b):
+        for ta, tb in zip(ra, rb):
+            assert torch.equal(ta, tb)
+    if ops.mfma_mode() == "split_f16":
+        # the first step registers the forms one by one; from the second step on, per model: one pack launch at the first conv (which
+        # asks for the flipped filters of its input-gradient forms first: one flip launch) instead of ~70 single launches
+        second = calls_on[len(calls_on) - calls_on[::-1].index("step"):]
+        assert len(calls_on) - len(second) - 2 >= 40 and 2 <= len(second) <= 8, calls_on
