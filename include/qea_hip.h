@@ -395,8 +395,8 @@ int qea_lstm_layer_bwd_split(float* gates, const float* c, const float* dy, cons
 
 /* ABI v9: the same layer in ONE launch per pass (csrc/lstm_seq.hip): the time loop runs inside the kernel, a workgroup keeps its
  * W_hh slice in LDS for all T steps as two fp16 planes (qea_lstm_seq_pack: qea_lstm_seq_pack_bytes() bytes per direction and form,
- * the two directions' copies contiguous; w_absmax receives the direction's largest |W_hh|, the scale of the planes: [2] floats for
- * the layer), c / dc stay in registers, and the eight workgroups of a (row block, direction) exchange h[t] (forward) or the gate
+ * the two directions' copies contiguous; w_absmax: a device float >= the direction's largest |W_hh|, e.g. qea_absmax's — the scale
+ * source of the planes; the layer calls take the two directions' values as [2] floats), c / dc stay in registers, and the eight workgroups of a (row block, direction) exchange h[t] (forward) or the gate
  * gradients (backward) through global memory with write-through stores, one arrival counter per group and sc1 loads — no
  * grid-wide barrier, no residency requirement beyond the group's own eight workgroups, every spin bounded (on a timeout the outputs
  * are NaN).  Three v_mfma_f32_32x32x16_f16 per product (|h| < 1 and W_hh by its abs-max; the gate gradients by a per-row,
@@ -404,7 +404,7 @@ int qea_lstm_layer_bwd_split(float* gates, const float* c, const float* dy, cons
  * Buffers and results as qea_lstm_layer_fwd / _bwd (no dc_scratch). */
 size_t qea_lstm_seq_pack_bytes(void);
 size_t qea_lstm_seq_workspace_bytes(int32_t B);
-int qea_lstm_seq_pack(const float* w_hh, void* planes_fwd, void* planes_bwd, float* w_absmax, void* stream);
+int qea_lstm_seq_pack(const float* w_hh, void* planes_fwd, void* planes_bwd, const float* w_absmax, void* stream);
 int qea_lstm_seq_fwd(float* gates, float* c, float* y, const void* planes_fwd, const float* w_absmax, int32_t T, int32_t B,
                      void* workspace, void* stream);
 int qea_lstm_seq_bwd(float* gates, const float* c, const float* dy, const void* planes_bwd, const float* w_absmax, int32_t T,

@@ -50,25 +50,6 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), x);
 }
 
-// abs-max of one W_hh (finite values only) -> out[0]
-__global__ __launch_bounds__(1024) void whh_absmax_kernel(const float* __restrict__ w, float* __restrict__ out) {
-  __shared__ float red[16];
-  float m = 0.f;
-  for (int i = threadIdx.x; i < GATES * HID; i += 1024) {
-    const float a = fabsf(w[i]);
-    if (a <= 3.4028234e38f) m = fmaxf(m, a);
-  }
-#pragma unroll
-  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-    out[0] = m;
-  }
-}
-
 // planes[u][ks][j][plane][lane][8] <- s * Wt[n][k], n = j*tile_stride + u*32 + (lane & 31), k = ks*16 + (lane >> 5)*8 + e
 // perm (backward form): k-step ks = (producer u' = ks >> 3, gate j = (ks >> 1) & 3, half = ks & 1) covers columns j*256 + u'*32 + half*16 ..
 __global__ void pack16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, const float* __restrict__ amax, int NT, int KSTEPS,
@@ -642,10 +623,9 @@ extern "C" size_t qea_lstm_seq_workspace_bytes(int32_t B) {   // enough for eith
   return f > b ? f : b;
 }
 
-extern "C" int qea_lstm_seq_pack(const float* w_hh, void* planes_fwd, void* planes_bwd, float* w_absmax, void* stream) {
+extern "C" int qea_lstm_seq_pack(const float* w_hh, void* planes_fwd, void* planes_bwd, const float* w_absmax, void* stream) {
   QEA_REQUIRE(w_hh && w_absmax && (planes_fwd || planes_bwd), "qea_lstm_seq_pack: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(whh_absmax_kernel, dim3(1), dim3(1024), 0, s, w_hh, w_absmax);
   // forward: Wt = W_hh [1024][256]: four gate tiles (rows j*256 + unit), K = 256 -> 16 k-steps
   if (planes_fwd) hipLaunchKernelGGL(pack16_kernel, dim3(qea_cdiv(8 * 16 * 4 * 64, 256)), dim3(256), 0, s, w_hh, (_Float16*)planes_fwd, w_absmax, 4, 16, HID, (long long)HID, 1LL, 8 * 16 * 4 * 64, 0);
   // backward: Wt[n][k] = W_hh[k][n], n < 256, K = 1024 -> 64 k-steps in (producer, gate, half) order, one tile

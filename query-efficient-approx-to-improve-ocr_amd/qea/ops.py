@@ -68,8 +68,31 @@ WEIGHT_CACHE = {"on": True}
 CAPTURE = {"token": None}
 
 
-def bump_weight_epoch():
+def bump_weight_epoch(params=None):
+    """Derived weight forms are stale from here on.  params: the parameters a raw-pointer writer has just touched — when every one of
+    them lives in a flat parameter buffer, only the forms of those models go stale (the fused Adam of one model must not make
+    the other model's filters be re-packed: round 4 found every form built twice per step); otherwise, or without
+    params, everything."""
+    if params is not None:
+        from .params import flat_state_of
+        seen = {}
+        for p_ in params:
+            fs = flat_state_of(p_, check=False)
+            if fs is None:
+                seen = None
+                break
+            seen[id(fs)] = fs
+        if seen:
+            for fs in seen.values():
+                fs.epoch += 1
+            return
     _wepoch[0] += 1
+
+
+def _model_epoch(w):
+    from .params import flat_state_of
+    fs = flat_state_of(w, check=False)
+    return fs.epoch if fs is not None else 0
 
 
 def weight_cached(kind, w, build, also=(), extra=None, batch=None):
@@ -87,7 +110,7 @@ def weight_cached(kind, w, build, also=(), extra=None, batch=None):
     if not WEIGHT_CACHE["on"]:
         return build()
     key = (kind, id(w))
-    ver = (w.data_ptr(), w._version, _wepoch[0], _stream(), token, extra) + tuple((id(t), t.data_ptr(), t._version) for t in also)
+    ver = _cache_ver(w, also, token, extra)
     hit = _wcache.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is w:
         return hit[1]
@@ -127,7 +150,7 @@ class FormJob:
 
 
 def _cache_ver(w, also, token, extra=None):
-    return (w.data_ptr(), w._version, _wepoch[0], _stream(), token, extra) + tuple((id(t), t.data_ptr(), t._version) for t in also)
+    return (w.data_ptr(), w._version, _wepoch[0], _model_epoch(w), _stream(), token, extra) + tuple((id(t), t.data_ptr(), t._version, _model_epoch(t)) for t in also)
 
 
 def _batched_forms(key, w, also, job, token):
@@ -388,7 +411,8 @@ def filter_absmax(w_src, w, ld, M, Cc):
     # keyed on the version counters of ALL the model's parameters (fs.vsum, refreshed by the engines' ensure_flat() walk before
     # every forward): a torch-side write to one re-homed parameter moves that parameter's _version, not the flat buffer's, and a
     # bound taken before e.g. load_state_dict would scale the new, larger filter to inf in its h plane
-    return weight_cached("flat_absmax", fs.data, lambda: absmax(fs.data, fs.total, 1, fs.total), extra=fs.vsum)
+    # ... and on the model's own epoch (the fused Adam writes through raw pointers and bumps only that)
+    return weight_cached("flat_absmax", fs.data, lambda: absmax(fs.data, fs.total, 1, fs.total), extra=(fs.vsum, fs.epoch))
 
 
 def split_planes_f16(x, ld, M, Cc, w_src=None):
@@ -666,7 +690,9 @@ def lstm_packs(whf, whr):
             nb = _lib.lib().qea_lstm_seq_pack_bytes()
             pf_ = torch.empty(2, nb, dtype=torch.uint8, device=dev)
             pb_ = torch.empty(2, nb, dtype=torch.uint8, device=dev)
-            am = torch.empty(2, device=dev)
+            # the scale source of the planes: any bound >= max |W_hh| (the model's flat abs-max when the weight lives in one: no launch)
+            bounds = [filter_absmax(("fwd", wh), wh, 256, 1024, 256) for wh in (whf, whr)]
+            am = torch.cat([b.reshape(1) for b in bounds])
             for d_, wh in enumerate((whf, whr)):
                 _lib.check(_lib.lib().qea_lstm_seq_pack(_ptr(wh), _ptr(pf_[d_]), _ptr(pb_[d_]), _ptr(am[d_:]), _stream()), "qea_lstm_seq_pack")
             return (pf_, am), (pb_, am)

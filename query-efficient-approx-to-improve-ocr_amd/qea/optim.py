@@ -54,7 +54,8 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        ops.bump_weight_epoch()                              # derived weight forms (qea.ops.weight_cached) are stale from here on
+        # derived weight forms (qea.ops.weight_cached) of the models this optimiser owns are stale from here on
+        ops.bump_weight_epoch([p for g in self.param_groups for p in g["params"]])
         for gi, group in enumerate(self.param_groups):
             ps = group["params"]
             if not ps or all(p.grad is None for p in ps):

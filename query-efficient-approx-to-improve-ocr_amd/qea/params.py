@@ -62,6 +62,7 @@ class FlatState:
             p.grad = gview
             self.grad_views.append(gview)
         self.by_id = {id(p): p for _, p in self.params}
+        self.epoch = 0                                       # bumped by writers that touch only this model's parameters (qea.ops.bump_weight_epoch)
         for _, p in self.params:
             _REGISTRY[id(p)] = weakref.ref(self)
         # BatchNorm buffers: running stats in one fp32 buffer, step counters in one int64 buffer

@@ -900,3 +900,60 @@ def test_batched_weight_forms_give_the_same_step():
         # asks for the flipped filters of its input-gradient forms first: one flip launch) instead of ~70 single launches
         second = calls_on[len(calls_on) - calls_on[::-1].index("step"):]
         assert len(calls_on) - len(second) - 2 >= 40 and 2 <= len(second) <= 8, calls_on
+
+
+def test_fused_adam_of_one_model_leaves_the_other_models_forms_alone():
+    """qea.optim.FusedAdam writes the weights through raw pointers and declares it with ops.bump_weight_epoch(its parameters): only
+    the forms (planes, flipped filters, the flat abs-max) of THAT model go stale.  After a CRNN-only step the UNet's cached forms
+    are the same objects, the CRNN's are new, and the next pass equals a pass with the cache switched off bit for bit."""
+    import weakref
+    from models.model_crnn import CRNN
+    from models.model_unet import UNet
+    from oracle import model_oracle as mo
+    from qea import ops
+    from qea.loss import CTCLoss
+    from qea.optim import FusedAdam
+    from qea.params import flat_state_of
+    labels = ["abc", "hello", "MI355X", "q"]
+    y, ysz = H.encode(labels)
+    x = torch.rand(4, 1, 32, 128, generator=torch.Generator().manual_seed(4)).cuda()
+    unet = _load(UNet(), mo.unet_state_shapes, 1).train()
+    crnn = _load(CRNN(95, False), mo.crnn_state_shapes, 2).train()
+    opt = FusedAdam(crnn.parameters(), lr=1e-3)
+
+    def pass_():
+        for m in (unet, crnn):
+            m.zero_grad(set_to_none=True)
+        lp = crnn(unet(x))
+        loss = CTCLoss()(lp, y, torch.full((4,), lp.shape[0], dtype=torch.int), ysz)
+        loss.backward()
+        return [loss.detach().clone()] + [p.grad.detach().clone() for p in list(unet.parameters()) + list(crnn.parameters())]
+
+    pass_()
+    pass_()                                                  # (the CRNN's flat buffer is made in the first pass, after the UNet's forward: that bumps everything once)
+    fs_u = flat_state_of(next(unet.parameters()))
+    before = {k: (v[1], v[2]()) for k, v in ops._wcache.items()}
+    opt.step()
+    got = pass_()
+    kept = rebuilt = 0
+    for k, (val, w) in before.items():
+        if w is None or k not in ops._wcache or not (torch.is_tensor(w) and w.is_cuda):
+            continue
+        fs = flat_state_of(w, check=False)
+        if fs is None:
+            continue
+        same = ops._wcache[k][1] is val
+        if fs is fs_u:
+            assert same, k
+            kept += 1
+        elif not same:
+            rebuilt += 1
+    assert kept >= 20 and rebuilt >= 10, (kept, rebuilt)
+    old = ops.WEIGHT_CACHE["on"]
+    ops.WEIGHT_CACHE["on"] = False
+    try:
+        want = pass_()
+    finally:
+        ops.WEIGHT_CACHE["on"] = old
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
