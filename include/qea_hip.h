@@ -401,14 +401,16 @@ int qea_lstm_layer_bwd_split(float* gates, const float* c, const float* dy, cons
  * grid-wide barrier, no residency requirement beyond the group's own eight workgroups, every spin bounded (on a timeout the outputs
  * are NaN).  Three v_mfma_f32_32x32x16_f16 per product (|h| < 1 and W_hh by its abs-max; the gate gradients by a per-row,
  * per-64-column-chunk scale taken in the kernel).  workspace: qea_lstm_seq_workspace_bytes(B) bytes, zeroed by the call itself.
- * Buffers and results as qea_lstm_layer_fwd / _bwd (no dc_scratch). */
+ * Buffers and results as qea_lstm_layer_fwd / _bwd (no dc_scratch).  y_absmax / dgates_absmax: NULL, or a ZEROED device float that
+ * receives the largest finite |y| / |gate gradient| of the pass (the scale source of the GEMMs that read the tensor next: no separate
+ * abs-max pass over it). */
 size_t qea_lstm_seq_pack_bytes(void);
 size_t qea_lstm_seq_workspace_bytes(int32_t B);
 int qea_lstm_seq_pack(const float* w_hh, void* planes_fwd, void* planes_bwd, const float* w_absmax, void* stream);
 int qea_lstm_seq_fwd(float* gates, float* c, float* y, const void* planes_fwd, const float* w_absmax, int32_t T, int32_t B,
-                     void* workspace, void* stream);
+                     void* workspace, float* y_absmax, void* stream);
 int qea_lstm_seq_bwd(float* gates, const float* c, const float* dy, const void* planes_bwd, const float* w_absmax, int32_t T,
-                     int32_t B, void* workspace, void* stream);
+                     int32_t B, void* workspace, float* dgates_absmax, void* stream);
 
 /* ABI v9 (additive).  Several derived weight forms in ONE launch (a model has ~110 of them per optimiser step, a few microseconds each):
  * kind 0 = qea_filter_flip_transpose (a, b, c, d = Co, Ci, KH, KW; amax unused), kind 1 = qea_pack_frag_planes_f16 (a, b = N, Cin),

@@ -96,6 +96,7 @@ struct SeqArgs {
   const _Float16* planes;  // [2 directions][W_PLANES_HALFS (+ trailer)]
   long long planes_dir;    // halfs between the directions
   const float* w_amax;     // [2] abs-max of the two W_hh
+  unsigned* out_amax;      // NULL, or a zeroed slot: receives the largest finite |h| (forward) / |gate gradient| (backward) as float bits
   unsigned* sync;          // [n_groups] arrival counters ... [n_groups_padded] timeout word
   char* xch;               // exchange area: [parity 2][direction 2][row block of 32][XRB bytes]
   int tmo_index;
@@ -184,6 +185,14 @@ __device__ __forceinline__ void publish(unsigned* ctr) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// non-negative floats order like their bit patterns: one atomic per wave into a zeroed slot
+__device__ __forceinline__ void publish_max(unsigned* slot, float m) {
+  if (slot == nullptr) return;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+}
+
 template <int AUX>
 __device__ __forceinline__ f32x4 load_x(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, AUX);   // aux 16 = sc1
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const SeqArgs p) {
   float creg[NE];
 #pragma unroll
   for (int i = 0; i < NE; ++i) creg[i] = 0.f;
+  float run_max = 0.f;                                 // the layer output's abs-max, carried by its producer (one atomic per wave at the end)
   bool failed = false;
   __syncthreads();                                     // the weight slice is in LDS
 
@@ -335,6 +345,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const SeqArgs p) {
       const float cc = gf * creg[i] + gi * gg;
       creg[i] = cc;
       hv[i] = failed ? __uint_as_float(0x7fc00000u) : go * tanh_fast(cc);
+      if (erow[i] < B) run_max = fmaxf(run_max, fabsf(hv[i]) <= 3.4028234e38f ? fabsf(hv[i]) : 0.f);
       go_[0][i] = gi; go_[1][i] = gf; go_[2][i] = gg; go_[3][i] = go;
     }
     // the exchange first: h of this tile as the next step's A fragments (k-steps 2u, 2u + 1 of the row block), write-through, and the
@@ -371,6 +382,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const SeqArgs p) {
     const __amdgpu_buffer_rsrc_t cdst = __builtin_amdgcn_make_buffer_rsrc(p.c + (size_t)t * B * (2 * HID), 0, B * (2 * HID) * 4, 0x00020000);
     store_tile<NE, 0>(Tw, creg, cdst, trow0, B, 2 * HID, d * HID + u * 32);
   }
+  publish_max(p.out_amax, run_max);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -415,6 +427,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
     const int r = RG == 4 ? i : 4 * w + i;
     erow[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
   }
+  float run_max = 0.f;                                  // the gate gradients' abs-max over all steps (one atomic per wave at the end)
   float dcreg[NE];
   int voffg[NE], voffc[NE];                             // byte offsets of (row, direction, unit) inside one time step of gates / of c, dy
 #pragma unroll
@@ -524,11 +537,14 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
       o_[2][i] = dc * gi * (1.f - gg * gg);
       o_[3][i] = dh * tc * go * (1.f - go);
       dcreg[i] = dc * gf;
+      float emax = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float av = fabsf(o_[j][i]);
-        tmax = fmaxf(tmax, av <= 3.4028234e38f ? av : 0.f);
+        emax = fmaxf(emax, av <= 3.4028234e38f ? av : 0.f);
       }
+      tmax = fmaxf(tmax, emax);
+      if (erow[i] < B) run_max = fmaxf(run_max, emax);
       if (failed) o_[0][i] = o_[1][i] = o_[2][i] = o_[3][i] = __uint_as_float(0x7fc00000u);
     }
     if (k + 1 < T) {
@@ -577,6 +593,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) store_tile<NE, 0>(Tw, o_[j], gdst, trow0, B, 2 * GATES, d * GATES + j * HID + u * 32);
   }
+  publish_max(p.out_amax, run_max);
 }
 
 // exchanged rows through L1 behind an agent acquire (true) or by sc1 loads (false), per kernel shape
@@ -635,11 +652,12 @@ extern "C" int qea_lstm_seq_pack(const float* w_hh, void* planes_fwd, void* plan
 }
 
 extern "C" int qea_lstm_seq_fwd(float* gates, float* c, float* y, const void* planes_fwd, const float* w_absmax, int32_t T, int32_t B, void* workspace,
-                                void* stream) {
+                                float* y_absmax, void* stream) {
   QEA_REQUIRE(gates && c && y && planes_fwd && w_absmax && workspace && T > 0 && B > 0, "qea_lstm_seq_fwd: bad arguments");
   QEA_REQUIRE((long long)B * (2 * GATES) * 4 < 0x7fffffffLL, "qea_lstm_seq_fwd: B too large for one buffer descriptor per time step");
   SeqArgs a = {};
   a.gates = gates; a.c = c; a.y = y;
+  a.out_amax = (unsigned*)y_absmax;
   a.planes = (const _Float16*)planes_fwd;
   a.planes_dir = W_PLANES_HALFS;
   a.w_amax = w_absmax;
@@ -654,11 +672,12 @@ extern "C" int qea_lstm_seq_fwd(float* gates, float* c, float* y, const void* pl
 }
 
 extern "C" int qea_lstm_seq_bwd(float* gates, const float* c, const float* dy, const void* planes_bwd, const float* w_absmax, int32_t T, int32_t B,
-                                void* workspace, void* stream) {
+                                void* workspace, float* dgates_absmax, void* stream) {
   QEA_REQUIRE(gates && c && dy && planes_bwd && w_absmax && workspace && T > 0 && B > 0, "qea_lstm_seq_bwd: bad arguments");
   QEA_REQUIRE((long long)B * (2 * GATES) * 4 < 0x7fffffffLL, "qea_lstm_seq_bwd: B too large for one buffer descriptor per time step");
   SeqArgs a = {};
   a.gates = gates; a.c = const_cast<float*>(c); a.dy = dy;
+  a.out_amax = (unsigned*)dgates_absmax;
   a.planes = (const _Float16*)planes_bwd;
   a.planes_dir = W_PLANES_HALFS;
   a.w_amax = w_absmax;

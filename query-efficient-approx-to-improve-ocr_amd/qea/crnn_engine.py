@@ -171,16 +171,18 @@ class CRNNEngine:
 
             pf, pb, split = ops.lstm_packs(whf, whr)               # W_hh in per-lane MFMA fragment order, both directions, fwd + bwd forms
             for d, suf in enumerate(("", "_reverse")):
-                bias = P[f"lstm.bias_ih_l{layer}{suf}"] + P[f"lstm.bias_hh_l{layer}{suf}"]
+                b_ih, b_hh = P[f"lstm.bias_ih_l{layer}{suf}"], P[f"lstm.bias_hh_l{layer}{suf}"]
+                bias = ops.weight_cached("lstm_bias_sum", b_ih, lambda b_ih=b_ih, b_hh=b_hh: (b_ih + b_hh).detach(), also=(b_hh,))
                 ops.conv_igemm(xin, P[f"lstm.weight_ih_l{layer}{suf}"], gates[:, :, d * 4 * HID:], B=1, H=1, W=T * B, Cin=512, OH=1,
                                OW=T * B, N=4 * HID, KH=1, KW=1, ldx=512, ldy=2 * 4 * HID, bias=bias,
                                w_src=("fwd", P[f"lstm.weight_ih_l{layer}{suf}"]), x_amax=xin_amax)
             cst = torch.empty(T, B, 2 * HID, device=dev)
             y = torch.empty(T, B, 2 * HID, device=dev)
-            ops.lstm_layer_fwd_any(gates, cst, y, pf, split, T, B)
-            # the layer output's abs-max (one pass): the next layer's projections / the Linear GEMM and, in the backward, the weight
-            # gradients that read y take it from here
-            y_amax = ops.absmax(y, 512, T * B, 512) if pool_ is not None else None
+            # the layer output's abs-max: the next layer's projections / the Linear GEMM and, in the backward, the weight gradients
+            # that read y take it from here — left by the one-launch layer kernel itself, else one pass
+            y_amax = slot()
+            if not ops.lstm_layer_fwd_any(gates, cst, y, pf, split, T, B, y_amax=y_amax):
+                y_amax = ops.absmax(y, 512, T * B, 512) if pool_ is not None else None
             lstm.append({"x": xin, "gates": gates, "c": cst, "y": y, "pb": pb, "split": split, "x_amax": xin_amax, "y_amax": y_amax})
             xin = y
         # Linear + log_softmax (vocab padded to a multiple of 32 columns; pad columns stay 0)
@@ -258,10 +260,11 @@ class CRNNEngine:
             s = ctx["lstm"][layer]
             gates, cst, yl, xin = s["gates"], s["c"], s["y"], s["x"]
             dc = None if s["split"] == "seq" else torch.empty(B, 2 * HID, device=dev)    # the one-launch kernels keep dc in registers
-            ops.lstm_layer_bwd_any(gates, cst, dy, s["pb"], s["split"], dc, T, B)          # gates now hold dgates
-            # ONE abs-max pass over the gate gradients serves the four weight-gradient GEMMs and the input-gradient GEMM of the layer
-            # (a bound over both directions and all steps scales every slice of the tensor)
-            g_amax = ops.absmax(gates, 8 * HID, TB, 8 * HID) if f16 else None
+            # ONE abs-max of the gate gradients serves the four weight-gradient GEMMs and the input-gradient GEMM of the layer (a bound
+            # over both directions and all steps scales every slice of the tensor): from the one-launch kernel, else one pass
+            g_amax = slot()
+            if not ops.lstm_layer_bwd_any(gates, cst, dy, s["pb"], s["split"], dc, T, B, g_amax=g_amax):      # gates now hold dgates
+                g_amax = ops.absmax(gates, 8 * HID, TB, 8 * HID) if f16 else None
             if param_grads:
                 def lstm_grads(layer=layer, gates=gates, xin=xin, yl=yl, g_amax=g_amax, x_amax=s.get("x_amax"), y_amax=s.get("y_amax")):
                     for d, suf in enumerate(("", "_reverse")):

@@ -716,25 +716,28 @@ def _lstm_seq_ws(B, dev):
     return torch.empty(_lib.lib().qea_lstm_seq_workspace_bytes(B), dtype=torch.uint8, device=dev)
 
 
-def lstm_layer_fwd_any(gates, c, y, pack, mode, T, B):
-    """mode: "seq" / "bf3" / "f32" (True / False of the round-2 callers = "bf3" / "f32")"""
+def lstm_layer_fwd_any(gates, c, y, pack, mode, T, B, y_amax=None):
+    """mode: "seq" / "bf3" / "f32" (True / False of the round-2 callers = "bf3" / "f32").  y_amax: a ZEROED abs-max slot; returns True
+    when the pass has left the layer output's abs-max in it (the one-launch kernels), else the caller makes its own pass."""
     if os.environ.get("QEA_LSTM_TRACE"):
         print("lstm fwd", mode, T, B, flush=True)
     if mode == "seq":
         planes, am = pack
         ws = _lstm_seq_ws(B, gates.device)
-        _lib.check(_lib.lib().qea_lstm_seq_fwd(_ptr(gates), _ptr(c), _ptr(y), _ptr(planes), _ptr(am), T, B, _ptr(ws), _stream()), "qea_lstm_seq_fwd")
+        _lib.check(_lib.lib().qea_lstm_seq_fwd(_ptr(gates), _ptr(c), _ptr(y), _ptr(planes), _ptr(am), T, B, _ptr(ws), _ptr(y_amax), _stream()), "qea_lstm_seq_fwd")
+        return y_amax is not None
     elif mode is True or mode == "bf3":
         _lib.check(_lib.lib().qea_lstm_layer_fwd_split(_ptr(gates), _ptr(c), _ptr(y), _ptr(pack), T, B, _stream()), "qea_lstm_layer_fwd_split")
     else:
         lstm_layer_fwd(gates, c, y, pack, T, B)
 
 
-def lstm_layer_bwd_any(gates, c, dy, pack, mode, dc_scratch, T, B):
+def lstm_layer_bwd_any(gates, c, dy, pack, mode, dc_scratch, T, B, g_amax=None):
     if mode == "seq":
         planes, am = pack
         ws = _lstm_seq_ws(B, gates.device)
-        _lib.check(_lib.lib().qea_lstm_seq_bwd(_ptr(gates), _ptr(c), _ptr(dy), _ptr(planes), _ptr(am), T, B, _ptr(ws), _stream()), "qea_lstm_seq_bwd")
+        _lib.check(_lib.lib().qea_lstm_seq_bwd(_ptr(gates), _ptr(c), _ptr(dy), _ptr(planes), _ptr(am), T, B, _ptr(ws), _ptr(g_amax), _stream()), "qea_lstm_seq_bwd")
+        return g_amax is not None
     elif mode is True or mode == "bf3":
         _lib.check(_lib.lib().qea_lstm_layer_bwd_split(_ptr(gates), _ptr(c), _ptr(dy), _ptr(pack), _ptr(dc_scratch), T, B, _stream()),
                    "qea_lstm_layer_bwd_split")

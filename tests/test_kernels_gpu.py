@@ -406,12 +406,18 @@ def test_lstm_layer_fwd_bwd(T, B, step):
         if step != "seq":
             (ops.lstm_pack_whh_split if split else ops.lstm_pack_whh)(P["w_hh" + s].detach().to(dev), pf[d], pb[d])
     c, y = torch.empty(T, B, 512, device=dev), torch.empty(T, B, 512, device=dev)
-    ops.lstm_layer_fwd_any(gates, c, y, pf, split, T, B)
+    ya, ga = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    carried = ops.lstm_layer_fwd_any(gates, c, y, pf, split, T, B, y_amax=ya)
     torch.cuda.synchronize()
     assert rel_err(y.cpu(), out.detach()) < 2e-5
+    assert bool(carried) == (step == "seq")
+    if carried:                                           # the one-launch kernel leaves the layer output's abs-max (exactly)
+        assert ya.item() == y.abs().max().item()
     dc = torch.empty(B, 512, device=dev)
-    ops.lstm_layer_bwd_any(gates, c, dy.to(dev), pb, split, dc, T, B)
+    carried = ops.lstm_layer_bwd_any(gates, c, dy.to(dev), pb, split, dc, T, B, g_amax=ga)
     torch.cuda.synchronize()
+    if carried:                                           # ... and the gate gradients'
+        assert ga.item() == gates.abs().max().item()
     # dgates -> dW_ih, db, dX via the generic kernels
     for d, s in enumerate(("", "_reverse")):
         dg = gates[:, :, d * 1024:]
