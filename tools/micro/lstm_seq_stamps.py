@@ -1,3 +1,6 @@
+"""In-kernel phase stamps of the one-launch BiLSTM kernels (profiles/r04_lstm_seq_lab.txt).  Needs a DEBUG build of csrc/lstm_seq.hip
+that records s_memrealtime per phase into a __device__ array and exports qea_lstm_seq_debug_read (the STAMP(...) patch of round 4,
+not part of the library): with the release library this script stops at the missing symbol."""
 import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "query-efficient-approx-to-improve-ocr_amd"))
