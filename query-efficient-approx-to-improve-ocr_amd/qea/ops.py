@@ -68,12 +68,15 @@ WEIGHT_CACHE = {"on": True}
 CAPTURE = {"token": None}
 
 
+MODEL_EPOCHS = {"on": os.environ.get("QEA_MODEL_EPOCHS", "1") != "0"}   # 0: every raw-pointer writer makes ALL derived forms stale (round-3 behaviour)
+
+
 def bump_weight_epoch(params=None):
     """Derived weight forms are stale from here on.  params: the parameters a raw-pointer writer has just touched — when every one of
     them lives in a flat parameter buffer, only the forms of those models go stale (the fused Adam of one model must not make
     the other model's filters be re-packed: round 4 found every form built twice per step); otherwise, or without
     params, everything."""
-    if params is not None:
+    if params is not None and MODEL_EPOCHS["on"]:
         from .params import flat_state_of
         seen = {}
         for p_ in params:

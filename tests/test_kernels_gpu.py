@@ -318,6 +318,8 @@ def test_lstm_seq_is_bit_identical_under_concurrent_load(B):
     start at different times and some wait for a CU.  The kernels are deterministic: every run must equal the idle run bit for bit
     (B = 70: groups spread over the XCDs; 600: 128-row forward, 32-row backward; 1300: 128-row both, ragged last row block)."""
     from qea import ops
+    if ops.mfma_mode() != "split_f16":
+        pytest.skip("the one-launch layer kernels are the fp16-split mode's")
     dev, T = "cuda", 31
     g = torch.Generator().manual_seed(B)
     wf, wr = (torch.randn(1024, 256, generator=g) / 16).to(dev), (torch.randn(1024, 256, generator=g) / 16).to(dev)
@@ -383,6 +385,8 @@ def test_lstm_layer_fwd_bwd(T, B, step):
         ops.conv_igemm(xd, P["w_ih" + s].detach().to(dev), gates[:, :, d * 1024:], B=1, H=1, W=T * B, Cin=In, OH=1, OW=T * B,
                        N=1024, KH=1, KW=1, ldx=In, ldy=2048, bias=bias)
     split = step == "split"
+    if step == "seq" and ops.mfma_mode() != "split_f16":
+        pytest.skip("the one-launch layer kernels are the fp16-split mode's")
     if step == "seq":
         # one launch per pass: W_hh in LDS as fp16 planes, h / gate gradients exchanged inside the launch (csrc/lstm_seq.hip);
         # 32-row workgroups up to 512 rows, 128-row ones above

@@ -780,7 +780,8 @@ def test_bn_backward_sums_from_the_dgrad_epilogue():
     finally:
         ops.bn_bwd = real_bn_bwd
         unet_engine.FUSE_BN_BWD_SUMS = True
-    assert fused_calls == [9, 0], fused_calls          # BatchNorm1 of the nine blocks took its sums from the dgrad epilogue
+    # BatchNorm1 of the nine blocks took its sums from the dgrad epilogue (an epilogue of the fp16-split LDS-halo kernel only)
+    assert fused_calls == ([9, 0] if ops.mfma_mode() == "split_f16" else [0, 0]), fused_calls
     worst = 0.0
     for u, v in zip(*res):
         den = v.double().norm().item()
@@ -932,7 +933,9 @@ def test_fused_adam_of_one_model_leaves_the_other_models_forms_alone():
     pass_()
     pass_()                                                  # (the CRNN's flat buffer is made in the first pass, after the UNet's forward: that bumps everything once)
     fs_u = flat_state_of(next(unet.parameters()))
-    before = {k: (v[1], v[2]()) for k, v in ops._wcache.items()}
+    import gc
+    gc.collect()                                             # (entries of dead models leave through weakref callbacks: not while we walk the dict)
+    before = {k: (v[1], v[2]()) for k, v in list(ops._wcache.items())}
     opt.step()
     got = pass_()
     kept = rebuilt = 0
