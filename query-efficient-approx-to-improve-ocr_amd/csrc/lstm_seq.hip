@@ -23,8 +23,11 @@
 //     the fp32 rows for itself, was VALU-bound: 30 us per backward step at B = 2048).  The exchange area is double-buffered by step
 //     parity (a producer two steps ahead has passed the wait every reader of that buffer arrived at after its loads).
 // Backward: dh_rec = dgates[e_prev] * W_hh over K = 1024 in eight chunks = the eight producers' 128 columns each, every chunk split to
-// fp16 by its producer with a PER-ROW scale taken from the chunk itself (the gate gradients have no a-priori bound):
-// acc += (chunk product) * 2^-scale(row, producer).  K runs in (producer, gate, half) order; qea_lstm_seq_pack orders W_hh^T to match.
+// fp16 by its producer with ONE scale per 32-row tile taken from the tile itself (the gate gradients have no a-priori bound; finer
+// than the one-per-tensor scale of the convolutions): acc += (chunk product) * 2^-scale(row block, producer).  K runs in (producer,
+// gate, half) order; qea_lstm_seq_pack orders W_hh^T to match.
+// The passes also leave the abs-max of what they produce (layer output / gate gradients: per-wave running maxima, one atomic per wave
+// at the end) for the GEMMs that read those tensors next.
 //
 // Roofline: HBM — per step and direction the gate tensor is read and written once (B x 1024 floats each way); the MFMA work is
 // 2 * B * 1024 * 256 flops per direction and step (x 3 for the split).
@@ -84,9 +87,7 @@ __global__ void pack16_kernel(const float* __restrict__ src, _Float16* __restric
   *reinterpret_cast<f16x8*>(o + 512) = pl;
 }
 
-#ifndef SEQ_NBUF4
-#define SEQ_NBUF4 3
-#endif
+constexpr int SEQ_NBUF4 = 3;                                     // chunk buffers of the 128-row backward (2 .. 6 measured: 818 / 819 / 899 / 1081 / 1371 us)
 
 struct SeqArgs {
   float* gates;            // [T][B][2 * 1024]
