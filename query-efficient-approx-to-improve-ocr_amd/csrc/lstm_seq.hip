@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const SeqArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     if (step > 0) {
-      if (!wait_arrivals<ACQ>(ctr, 8u * step, tmo)) failed = true;
+      if (!failed && !wait_arrivals<ACQ>(ctr, 8u * step, tmo)) failed = true;   // after one timeout the polling lane stops waiting: the launch ends at once, NaN in its outputs
       __syncthreads();
       const __amdgpu_buffer_rsrc_t xsrc =
           __builtin_amdgcn_make_buffer_rsrc(p.xch + ((size_t)((((step - 1) & 1) * 2 + d) * p.nrb + rb)) * XRB_FWD, 0, XRB_FWD, 0x00020000);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const SeqArgs p) {
       load_operands();
     } else {
       if constexpr (RG == 1) load_operands();           // 28 registers: ahead of the wait
-      if (!wait_arrivals<ACQ>(ctr, 8u * k, tmo)) failed = true;
+      if (!failed && !wait_arrivals<ACQ>(ctr, 8u * k, tmo)) failed = true;
       __syncthreads();
       const __amdgpu_buffer_rsrc_t xsrc =
           __builtin_amdgcn_make_buffer_rsrc(p.xch + ((size_t)((((k - 1) & 1) * 2 + d) * p.nrb + rb)) * XRB_BWD, 0, XRB_BWD, 0x00020000);
