@@ -124,3 +124,49 @@ def test_wgrad_bit_reproducible_and_conv_linear():
     a, b, ab = conv(x), conv(x2), conv(x + x2)
     assert (ab - (a + b)).abs().max().item() <= 2e-5 * ab.abs().max().item()
     assert torch.equal(conv(2 * x), 2 * a)
+
+
+def test_bilstm_layer_at_full_size_one_launch_vs_steps():
+    """BASELINE configs[2] size (T = 31, B = 2048, 128-row workgroups, 256 of them, both exchange parities in use for 30 steps):
+    the one-launch layer kernels (csrc/lstm_seq.hip) against the per-step split-bf16 kernels on the same inputs (forward output and
+    gate gradients within 1e-6 relative: two fp32-class arithmetics), bit-reproducible run to run, the carried abs-max values exact,
+    and a batch-split property: rows 0..1279 of the full batch equal a B = 1280 launch of those rows bit for bit (a row block's result
+    depends on no other row block; both sizes run the 128-row workgroups — the 32-row shape of smaller batches sums the eight K chunks in
+    another association and agrees to rounding only)."""
+    from qea import ops
+    if ops.mfma_mode() != "split_f16":
+        pytest.skip("the one-launch layer kernels are the fp16-split mode's")
+    dev, T, B = "cuda", 31, 2048
+    g = torch.Generator().manual_seed(77)
+    wf, wr = (torch.randn(1024, 256, generator=g) / 16).to(dev), (torch.randn(1024, 256, generator=g) / 16).to(dev)
+    gx = (torch.randn(T, B, 2048, generator=g) * 0.5).to(dev)
+    dy = torch.randn(T, B, 512, generator=g).to(dev)
+
+    def layer(mode_on, gx_, dy_, Bn):
+        old = ops.LSTM_SEQ["on"]
+        ops.LSTM_SEQ["on"] = mode_on
+        try:
+            pf, pb, mode = ops.lstm_packs(wf, wr)
+        finally:
+            ops.LSTM_SEQ["on"] = old
+        gates, c, y = gx_.clone(), torch.empty(T, Bn, 512, device=dev), torch.empty(T, Bn, 512, device=dev)
+        ya, ga = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        ops.lstm_layer_fwd_any(gates, c, y, pf, mode, T, Bn, y_amax=ya)
+        dc = None if mode == "seq" else torch.empty(Bn, 512, device=dev)
+        ops.lstm_layer_bwd_any(gates, c, dy_, pb, mode, dc, T, Bn, g_amax=ga)
+        torch.cuda.synchronize()
+        return y, gates, ya, ga
+
+    y1, g1, ya, ga = layer(True, gx, dy, B)
+    y2, g2, _, _ = layer(True, gx, dy, B)
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)                      # run to run
+    assert torch.isfinite(y1).all() and torch.isfinite(g1).all()
+    assert ya.item() == y1.abs().max().item() and ga.item() == g1.abs().max().item()
+    ys, gs, _, _ = layer(False, gx, dy, B)                                  # the per-step kernels
+    assert ((y1 - ys).norm() / ys.norm()).item() < 1e-6
+    assert ((g1 - gs).norm() / gs.norm()).item() < 1e-6
+    yh, gh, _, _ = layer(True, gx[:, :1280].contiguous(), dy[:, :1280].contiguous(), 1280)
+    assert torch.equal(yh, y1[:, :1280]) and torch.equal(gh, g1[:, :1280])
+    yq, gq, _, _ = layer(True, gx[:, :512].contiguous(), dy[:, :512].contiguous(), 512)          # 32-row workgroups
+    assert ((yq - y1[:, :512]).norm() / y1[:, :512].norm()).item() < 1e-6   # (forward: the four gates meet through LDS, same sums)
+    assert ((gq - g1[:, :512]).norm() / g1[:, :512].norm()).item() < 1e-6
